@@ -1,0 +1,209 @@
+/*
+ * wnhip.h — C ABI of libwnhip.so, the MI355X (gfx950) generation engine that
+ * replaces the TensorFlow graph execution on the generation path of
+ * bfs18/nsynth_wavenet.
+ *
+ * The reference exposes NO native/FFI interface for this path (it is pure
+ * Python over TensorFlow 1.x).  Its seam is Python:
+ *     wavenet/parallelgen.py:22   synthesis(hparams, mel, save_paths, checkpoint_path)
+ *     wavenet/fastgen.py:69       encode(hparams, wav_data, checkpoint_path)
+ *     wavenet/fastgen.py:128      synthesis(hparams, mel_encoding, save_paths, checkpoint_path)
+ * and inside those, one `sess.run` on the graphs built by
+ *     wavenet/parallel_wavenet.py:289-359   ParallelWavenet.feed_forward + _clip_quant_scale
+ *     wavenet/wavenet.py:142-155            Wavenet.deconv_stack
+ *     wavenet/wavenet.py:379-514            Fastgen.sample
+ * Each entry point below states which of those `sess.run` calls it replaces.
+ * The ctypes binding a maintainer of the reference would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain C, no torch / HIP types in signatures: a stream is passed as the
+ *     raw hipStream_t value in a `void*` (NULL = the null stream).
+ *   - Every pointer is a DEVICE pointer unless its name ends in `_host`.
+ *   - The caller owns every input, output and workspace buffer; the library
+ *     owns only the handle and its packed weights.  No allocation and no host
+ *     synchronisation happens inside the generate calls (wn_ar_generate, whose
+ *     sample loop is driven from the host, is the documented exception: it
+ *     enqueues work and returns without synchronising, but it instantiates a
+ *     hipGraph).
+ *   - Return value: 0 on success, a negative errno-style code otherwise
+ *     (WN_EINVAL shape/config, WN_ENOENT unknown/missing weight, WN_ENOMEM
+ *     workspace too small, WN_EIO HIP runtime error, WN_ESTATE wrong call
+ *     order).  Nothing throws or aborts across the ABI; the message is
+ *     available from wn_last_error().
+ *   - A handle is immutable after wn_finalize() and may be shared by
+ *     concurrent callers that use distinct workspaces and streams.
+ */
+#ifndef WNHIP_H_
+#define WNHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+
+#define WN_OK       0
+#define WN_EINVAL  (-22)
+#define WN_ENOENT  (-2)
+#define WN_ENOMEM  (-12)
+#define WN_EIO     (-5)
+#define WN_ESTATE  (-1)
+
+#define WN_MAX_DECONV 4
+#define WN_MAX_FLOWS  8
+
+/* kind */
+#define WN_KIND_STUDENT 0   /* ParallelWavenet (IAF), parallel_wavenet.py */
+#define WN_KIND_TEACHER 1   /* Wavenet / Fastgen (autoregressive), wavenet.py */
+/* loss_type */
+#define WN_LOSS_CE       0
+#define WN_LOSS_MOL      1
+#define WN_LOSS_GAUSS    2
+#define WN_LOSS_LOGISTIC 3  /* student only: noise source (parallel_wavenet.py:303-306) */
+/* upsample_act (masked.py:28-36) */
+#define WN_ACT_TANH       0
+#define WN_ACT_RELU       1
+#define WN_ACT_LEAKY_RELU 2 /* alpha = 0.4 */
+
+/* Plain-C mirror of the config JSON (config_jsons/NAME.json) after the
+ * reference's per-class getattr defaults have been applied by the caller
+ * (wavenet.py:105-129,326-345; parallel_wavenet.py:124-141). */
+typedef struct wn_config {
+    int32_t kind;
+    int32_t n_mel;                          /* 80 (mel_extractor.py:17) */
+    int32_t width;                          /* residual channels */
+    int32_t skip_width;                     /* teacher only */
+    int32_t gate_width;                     /* student: width; teacher: width or 2*width */
+    int32_t deconv_width;
+    int32_t n_deconv;                       /* len(deconv_config) */
+    int32_t deconv_filter[WN_MAX_DECONV];
+    int32_t deconv_stride[WN_MAX_DECONV];
+    int32_t filter_length;                  /* 3 (masked.py:349 asserts it) */
+    int32_t num_stages;
+    int32_t num_layers;                     /* teacher */
+    int32_t n_flows;                        /* student: len(num_iaf_layers) */
+    int32_t iaf_layers[WN_MAX_FLOWS];
+    int32_t use_mu_law;
+    int32_t loss_type;
+    int32_t mol_mix;
+    int32_t out_width;                      /* teacher: 256/65536 (ce), 3*mol_mix, 2; student: 2 */
+    int32_t share_deconv;                   /* use_share_deconv || use_teacher_deconv */
+    int32_t use_weight_norm;
+    int32_t upsample_act;
+    int32_t reserved[8];
+} wn_config;
+
+typedef struct wn_handle wn_handle;
+
+int wn_abi_version(void);
+
+/* Build an empty engine for one model on the current HIP device.
+ * Replaces graph construction (parallelgen.py:11-19, fastgen.py:61-66,118-125). */
+int wn_create(const wn_config* cfg_host, wn_handle** out);
+
+/* Provide one variable under its TensorFlow name WITHOUT the
+ * '/ExponentialMovingAverage' suffix and ':0' (fastgen.py:12-14), in the
+ * reference's shape: conv kernels HWIO [1,K,Cin,Cout] '<scope>/W', biases
+ * '<scope>/biases' (masked.py:190-200); transposed-conv kernels [1,K,Cout,Cin]
+ * '<scope>/kernel', '<scope>/bias' (masked.py:249-260); weight-norm pairs
+ * '<name>_V','<name>_g' (masked.py:145-153).  Replaces Saver.restore
+ * (parallelgen.py:29-41, fastgen.py:80-84,142-147).  Unknown names -> WN_ENOENT. */
+int wn_set_weight(wn_handle* h, const char* tf_var_name,
+                  const float* data_host, const int64_t* shape_host, int rank);
+
+/* Check that every variable the config needs is present, fold weight-norm
+ * (W = V/||V||*g), repack into the kernels' MFMA-fragment order, upload. */
+int wn_finalize(wn_handle* h);
+
+/* Length helpers: samples produced for F mel frames.
+ *   IAF:  T  = (F*frame_shift // 2^(num_stages-1)) * 2^(num_stages-1)  (parallel_wavenet.py:293-302)
+ *   AR :  Tn = F*frame_shift                                          (fastgen.py:136,156)      */
+int64_t wn_iaf_length(const wn_handle* h, int F);
+int64_t wn_ar_length(const wn_handle* h, int F);
+
+/* Bytes of caller-provided scratch needed by wn_deconv / wn_iaf_generate /
+ * wn_ar_generate for batch B and F frames (Tn = wn_ar_length for AR). */
+size_t wn_workspace_bytes(const wn_handle* h, int B, int F);
+
+/* Wavenet.deconv_stack (wavenet.py:46-73,142-155): mel [B,F,n_mel] ->
+ * enc [B, F*frame_shift, deconv_width] in the REFERENCE layout (time-major),
+ * i.e. what fastgen.encode returns (fastgen.py:69-88).  `scope` is the
+ * variable-name prefix: "" (teacher), "iaf_share", "iaf_1", ... */
+int wn_deconv(wn_handle* h, const char* scope, const float* mel, int B, int F,
+              float* enc, void* ws, size_t ws_bytes, void* stream);
+
+/* The single sess.run of parallelgen.synthesis (parallelgen.py:43-45):
+ * ParallelWavenet.feed_forward (parallel_wavenet.py:289-345) followed by
+ * _clip_quant_scale (:347-359).
+ *   mel        [B,F,n_mel]
+ *   noise      [B,T] injected logistic/normal draws, or NULL -> drawn on the
+ *              device from `seed` (Philox4x32-10; logistic via log u - log(1-u),
+ *              u ~ U(1e-5,1-1e-5), or N(0,1) for loss_type gauss)
+ *   wav        [B,T]  float32 on the 2/Q grid (or the inverse-mu-law table)
+ *   idx        [B,T]  int32 quantisation index in [-Q/2,Q/2)        (optional)
+ *   x_raw      [B,T]  feed_forward's 'x' before clipping           (optional)
+ *   mean_tot, scale_tot [B,T] as returned by feed_forward          (optional)
+ *   rand_out   [B,T]  the noise actually used ('rand_input')       (optional) */
+int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F,
+                    const float* noise, uint64_t seed,
+                    float* wav, int32_t* idx, float* x_raw,
+                    float* mean_tot, float* scale_tot, float* rand_out,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* _clip_quant_scale on its own (parallel_wavenet.py:347-359 with
+ * utils.cast_quantize / inv_cast_quantize / inv_mu_law, utils.py:108-159):
+ * x[n] -> wav[n], idx[n].  Bit-exact integer index. */
+int wn_clip_quant(wn_handle* h, const float* x, int64_t n,
+                  float* wav, int32_t* idx, void* stream);
+
+/* ---- autoregressive path (wavenet.py:379-514, fastgen.py:118-169) ---- */
+
+/* Number of injected random values per sample and per batch element:
+ * mol: mol_mix uniforms for the Gumbel-max + 1 uniform for the logistic;
+ * gauss: 1 standard normal; ce: 1 uniform in [0,1) (inverse-CDF draw). */
+int wn_ar_n_rand(const wn_handle* h);
+
+/* Bytes of the explicit FIFO state (two queues per causal layer,
+ * masked.py:352-355) for batch B. */
+size_t wn_ar_state_bytes(const wn_handle* h, int B);
+
+/* sess.run(init_ops) (fastgen.py:150): zero the queues, step counter := 0. */
+int wn_ar_reset(wn_handle* h, void* state, int B, void* stream);
+
+/* One sess.run([sample, push_ops]) (fastgen.py:158-161):
+ *   wav_in   [B]      previous audio sample (float, already de-quantised)
+ *   enc_t    [B,deconv_width]  conditioning for this step
+ *   rnd      [B,n_rand] injected randoms, or NULL -> Philox(seed, step)
+ *   sample   [B]      int32 in [-Q/2,Q/2)
+ *   out_params [B,out_width] pre-sampling network output            (optional) */
+int wn_ar_step(wn_handle* h, void* state, int B,
+               const float* wav_in, const float* enc_t,
+               const float* rnd, uint64_t seed,
+               int32_t* sample, float* out_params, void* stream);
+
+/* The whole loop of fastgen.synthesis (fastgen.py:150-168) for Tn steps:
+ *   enc   [B,Tn,deconv_width]  (reference layout, e.g. from wn_deconv)
+ *   rnd   [Tn,B,n_rand] or NULL -> Philox(seed)
+ *   idx   [B,Tn] int32, wav [B,Tn] float (de-quantised feedback signal)
+ *   forced_wav [B,Tn] optional teacher forcing: when non-NULL the network input
+ *              at step t is forced_wav[:,t-1] instead of its own sample
+ *   out_params [B,Tn,out_width] optional */
+int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
+                   const float* rnd, uint64_t seed,
+                   int32_t* idx, float* wav,
+                   const float* forced_wav, float* out_params,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Last error message of this handle (or of wn_create when h == NULL). */
+const char* wn_last_error(const wn_handle* h);
+
+void wn_destroy(wn_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WNHIP_H_ */

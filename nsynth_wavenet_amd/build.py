@@ -1,0 +1,70 @@
+"""Builds libwnhip.so (the gfx950 HIP engine) in-tree with hipcc.
+
+    python -m nsynth_wavenet_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The shared object is written to
+nsynth_wavenet_amd/lib/libwnhip.so so that it travels with the source tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libwnhip.so')
+SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_ar.hip']
+HEADERS = ['wn_internal.h', 'wn_codec.h', os.path.join(ROOT, 'include', 'wnhip.h')]
+
+
+def find_hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + \
+           [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into one shared object."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    hipcc = find_hipcc()
+    common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
+              '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(s)[0] + '.o')
+        cmd = [hipcc] + common + (['-x', 'hip'] if s.endswith('.cpp') else []) + \
+              ['-c', os.path.join(CSRC, s), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for s, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors='replace'))
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on {}:\n{}'.format(s, out.decode(errors='replace')))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

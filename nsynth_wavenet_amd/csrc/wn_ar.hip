@@ -1,0 +1,525 @@
+// Autoregressive "fastgen" path on gfx950:
+//   wavenet/wavenet.py:379-514 (Fastgen.sample), wavenet/masked.py:328-405
+//   (causal_linear / linear), wavenet/loss_func.py:140-206 (sampling heads),
+//   wavenet/fastgen.py:128-169 (per-sample driver loop).
+//
+// The reference runs ONE python->TF->device round trip per audio sample with two
+// CPU FIFOQueues per causal layer.  Here the queues are device-resident rings
+// (slot = step mod 2*rate holds the layer INPUT of that step, masked.py:357-359),
+// the step counter lives in device memory, and every pointer a step needs is
+// derived on the device from that counter -- so one step is a static sequence of
+// GEMV kernels that is captured once in a hipGraph (AR_GRAPH_STEPS steps per
+// graph) and replayed; no host round trip per sample.
+//
+// Round-1 form: weights are streamed from L2/Infinity-Cache every step by
+// wave-per-output-row GEMV kernels (latency bound).
+#include "wn_internal.h"
+#include "wn_codec.h"
+
+
+namespace {
+
+constexpr int AR_BT = 4;            // batch elements per register tile
+constexpr int AR_GRAPH_STEPS = 16;  // steps captured per hipGraph
+constexpr int AR_HDR = 64;          // header floats (step counter lives in the first 8 bytes)
+
+struct ArDims {
+    int B, W, S, G, Cd, OW, Q, mu, loss, M;
+};
+
+// State blob (floats): [hdr 64][a_prev B][u ring 4*B][rings...][l B*W][s B*S][g B*G/2][z B*S][out B*OW][ebuf B*OW]
+struct ArStateLayout {
+    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, total;
+};
+
+ArStateLayout ar_state_layout(const wn_handle* h, int B) {
+    const wn_config& c = h->cfg;
+    ArStateLayout L;
+    size_t o = AR_HDR;
+    auto carve = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };
+    L.a_prev = carve(B);
+    L.uring = carve(4 * (size_t)B);
+    L.rings = carve(h->ar.ring_floats * B);
+    L.l = carve((size_t)B * c.width);
+    L.s = carve((size_t)B * c.skip_width);
+    L.g = carve((size_t)B * c.gate_width / 2);
+    L.z = carve((size_t)B * c.skip_width);
+    L.out = carve((size_t)B * c.out_width);
+    L.ebuf = carve((size_t)B * c.out_width);
+    L.total = o;
+    return L;
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ inline long long ar_step_of(const float* state) {
+    return *reinterpret_cast<const long long*>(state);
+}
+
+// ---- conv_start (wavenet.py:426-434): l = b + W0 u[t-2] + W1 u[t-1] + W2 u[t] ----
+// u[t] = encoded network input of step t = previous audio sample (fastgen.py:153-168)
+__global__ void ar_start_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
+                                const float* __restrict__ wav_in, const float* __restrict__ forced,
+                                int Tn, const float* __restrict__ wb) {
+    const long long t = ar_step_of(state);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B * D.W) return;
+    const int b = i / D.W, c = i - b * D.W;
+    float a;
+    if (wav_in) a = wav_in[b];                                  // wn_ar_step: explicit input
+    else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
+    else a = t > 0 ? state[L.a_prev + b] : 0.f;                 // fastgen.py:154: audio starts at 0
+    const float u = D.mu ? wn_mu_law_scaled(a) : a;
+    float* ur = state + L.uring;
+    const float u1 = ur[((t + 3) & 3) * D.B + b];               // u[t-1]
+    const float u2 = ur[((t + 2) & 3) * D.B + b];               // u[t-2]
+    state[L.l + (size_t)b * D.W + c] = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+    if (c == 0) ur[(t & 3) * D.B + b] = u;
+}
+
+// ---- generic row GEMV: y[b][o] (op)= bias[o] + W[o][:] . x[b][:]  (masked.py:383-405) ----
+// MODE 0: skip_start  s  = .            x = l
+// MODE 1: res/skip    l += . (o<W) and ring push of the old l; s += . (o>=W)   x = g
+// MODE 2: out1        z  = relu(.)      x = [relu(s) | enc_t]
+// MODE 3: out2        out = .           x = z
+template <int MODE>
+__global__ __launch_bounds__(256) void ar_rows_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Wm,
+    const float* __restrict__ bias, int rows, int K, const float* __restrict__ enc, int Tn, int per_step,
+    size_t ring_off, int dil) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= rows) return;
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const float* wrow = Wm + (size_t)o * K;
+    const float bo = bias[o];
+    for (int b0 = 0; b0 < D.B; b0 += AR_BT) {
+        float acc[AR_BT];
+#pragma unroll
+        for (int e = 0; e < AR_BT; ++e) acc[e] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f4 w = *reinterpret_cast<const f4*>(wrow + k);
+#pragma unroll
+            for (int e = 0; e < AR_BT; ++e) {
+                const int b = b0 + e;
+                if (b < D.B) {
+                    f4 xv;
+                    if (MODE == 0) xv = *reinterpret_cast<const f4*>(state + L.l + (size_t)b * D.W + k);
+                    else if (MODE == 1) xv = *reinterpret_cast<const f4*>(state + L.g + (size_t)b * (D.G / 2) + k);
+                    else if (MODE == 2) {
+                        if (k < D.S) {
+                            xv = *reinterpret_cast<const f4*>(state + L.s + (size_t)b * D.S + k);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xv[i] = fmaxf(xv[i], 0.f);          // wavenet.py:494
+                        } else {
+                            xv = *reinterpret_cast<const f4*>(enc + ((size_t)b * Tn + ti) * D.Cd + (k - D.S));
+                        }
+                    } else xv = *reinterpret_cast<const f4*>(state + L.z + (size_t)b * D.S + k);
+                    acc[e] += w[0] * xv[0] + w[1] * xv[1] + w[2] * xv[2] + w[3] * xv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < AR_BT; ++e) {
+            const int b = b0 + e;
+            if (b >= D.B) break;
+            const float v = wave_sum(acc[e]) + bo;
+            if (lane == 0) {
+                if (MODE == 0) state[L.s + (size_t)b * D.S + o] = v;
+                else if (MODE == 1) {
+                    if (o < D.W) {
+                        float* lp = state + L.l + (size_t)b * D.W + o;
+                        const float lold = *lp;
+                        // push the layer INPUT into slot t mod 2d (masked.py:357-359)
+                        state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil)) * D.B + b) * D.W + o] = lold;
+                        *lp = lold + v;
+                    } else {
+                        state[L.s + (size_t)b * D.S + (o - D.W)] += v;
+                    }
+                } else if (MODE == 2) state[L.z + (size_t)b * D.S + o] = fmaxf(v, 0.f);   // wavenet.py:499
+                else state[L.out + (size_t)b * D.OW + o] = v;
+            }
+        }
+    }
+}
+
+// ---- dilated causal_linear + conditioning + gate (wavenet.py:456-479, masked.py:369-376) ----
+// one wave = gate pair (o, o+m): x = [ring[t-2d] | ring[t-d] | l | enc_t], K = 3W + Cd
+__global__ __launch_bounds__(256) void ar_gate_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Wm,
+    const float* __restrict__ bias, const float* __restrict__ enc, int Tn, int per_step, size_t ring_off,
+    int dil) {
+    const int lane = threadIdx.x & 63;
+    const int m = D.G / 2;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= m) return;
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const int K = 3 * D.W + D.Cd;
+    const float* w0 = Wm + (size_t)o * K;
+    const float* w1 = Wm + (size_t)(o + m) * K;
+    const float* ring = state + L.rings + (size_t)D.B * ring_off;
+    const size_t slot2 = (size_t)(t % (2 * dil)) * D.B;            // x[t-2d]
+    const size_t slot1 = (size_t)((t + dil) % (2 * dil)) * D.B;    // x[t-d]
+    for (int b0 = 0; b0 < D.B; b0 += AR_BT) {
+        float a0[AR_BT], a1[AR_BT];
+#pragma unroll
+        for (int e = 0; e < AR_BT; ++e) a0[e] = a1[e] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f4 wa = *reinterpret_cast<const f4*>(w0 + k);
+            const f4 wb = *reinterpret_cast<const f4*>(w1 + k);
+#pragma unroll
+            for (int e = 0; e < AR_BT; ++e) {
+                const int b = b0 + e;
+                if (b < D.B) {
+                    const float* src;
+                    if (k < D.W) src = ring + (slot2 + b) * D.W + k;
+                    else if (k < 2 * D.W) src = ring + (slot1 + b) * D.W + (k - D.W);
+                    else if (k < 3 * D.W) src = state + L.l + (size_t)b * D.W + (k - 2 * D.W);
+                    else src = enc + ((size_t)b * Tn + ti) * D.Cd + (k - 3 * D.W);
+                    const f4 xv = *reinterpret_cast<const f4*>(src);
+                    a0[e] += wa[0] * xv[0] + wa[1] * xv[1] + wa[2] * xv[2] + wa[3] * xv[3];
+                    a1[e] += wb[0] * xv[0] + wb[1] * xv[1] + wb[2] * xv[2] + wb[3] * xv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < AR_BT; ++e) {
+            const int b = b0 + e;
+            if (b >= D.B) break;
+            const float hs = wave_sum(a0[e]) + bias[o];
+            const float ht = wave_sum(a1[e]) + bias[o + m];
+            if (lane == 0)
+                state[L.g + (size_t)b * m + o] = (1.f / (1.f + expf(-hs))) * tanhf(ht);   // wavenet.py:479
+        }
+    }
+}
+
+// ---- sampling heads (loss_func.py:140-206) + feedback de-quantisation (fastgen.py:163-167) ----
+// one workgroup per batch element
+__global__ __launch_bounds__(256) void ar_sample_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ rnd, int n_rand,
+    uint64_t seed, int per_step, int Tn, int* __restrict__ idx, float* __restrict__ wav,
+    float* __restrict__ out_params) {
+    __shared__ float red[256];
+    __shared__ float sel_val[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const float* out = state + L.out + (size_t)b * D.OW;
+    if (out_params)
+        for (int i = tid; i < D.OW; i += 256) out_params[((size_t)b * Tn + ti) * D.OW + i] = out[i];
+
+    // randoms: injected [Tn][B][n_rand] or Philox(seed; step, batch, lane)
+    auto rnd_at = [&](int j) -> float {
+        if (rnd) return rnd[((size_t)ti * D.B + b) * n_rand + j];
+        uint32_t c[4] = {(uint32_t)t, (uint32_t)(t >> 32), (uint32_t)b, (uint32_t)(j >> 2) + 0x41520000u};
+        wn_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        if (D.loss == WN_LOSS_GAUSS) {
+            const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * wn_u01(c[1]));
+        }
+        const float u = wn_u01(c[j & 3]);
+        return D.loss == WN_LOSS_CE ? u : u * (1.f - 2e-5f) + 1e-5f;
+    };
+
+    int q = 0;
+    if (D.loss == WN_LOSS_MOL) {
+        // loss_func.py:154-186
+        if (tid < D.M) sel_val[tid] = out[tid] - logf(-logf(rnd_at(tid)));
+        __syncthreads();
+        if (tid == 0) {
+            int k = 0;
+            for (int i = 1; i < D.M; ++i) if (sel_val[i] > sel_val[k]) k = i;   // first max, like argmax
+            const float mean = out[D.M + k];
+            const float ls = fminf(fmaxf(out[2 * D.M + k], -7.f), 7.f);
+            const float u2 = rnd_at(D.M);
+            const float x = mean + expf(ls) * (logf(u2) - logf(1.f - u2));
+            q = wn_clip_quantize(x, D.Q);
+        }
+    } else if (D.loss == WN_LOSS_GAUSS) {
+        // loss_func.py:66-75,200-206
+        if (tid == 0) {
+            const float x = out[0] + expf(fmaxf(out[1], -7.f)) * rnd_at(0);
+            q = wn_clip_quantize(x, D.Q);
+        }
+    } else {
+        // categorical draw by inverse CDF from one uniform (sequential fp32 running sum)
+        float mx = -INFINITY;
+        for (int i = tid; i < D.OW; i += 256) mx = fmaxf(mx, out[i]);
+        red[tid] = mx;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+            __syncthreads();
+        }
+        mx = red[0];
+        float* e = state + L.ebuf + (size_t)b * D.OW;
+        for (int i = tid; i < D.OW; i += 256) e[i] = expf(out[i] - mx);
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int i = 0; i < D.OW; ++i) tot += e[i];
+            const float thr = rnd_at(0) * tot;
+            float run = 0.f;
+            int k = 0;
+            for (int i = 0; i < D.OW; ++i) {
+                run += e[i];
+                if (run <= thr) k = i + 1;
+            }
+            q = min(k, D.OW - 1) - D.Q / 2;                      // loss_func.py:149
+        }
+    }
+    if (tid == 0) {
+        const float a = wn_dequant(q, D.Q, D.mu);
+        state[L.a_prev + b] = a;
+        if (idx) idx[(size_t)b * Tn + ti] = q;
+        if (wav) wav[(size_t)b * Tn + ti] = a;
+    }
+}
+
+__global__ void ar_advance_kernel(float* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *reinterpret_cast<long long*>(state) += 1;
+}
+
+ArDims ar_dims(const wn_handle* h, int B) {
+    const wn_config& c = h->cfg;
+    ArDims D;
+    D.B = B; D.W = c.width; D.S = c.skip_width; D.G = c.gate_width; D.Cd = c.deconv_width;
+    D.OW = c.out_width; D.Q = c.use_mu_law ? 256 : 65536; D.mu = c.use_mu_law; D.loss = c.loss_type;
+    D.M = c.loss_type == WN_LOSS_MOL ? c.mol_mix : 0;
+    return D;
+}
+
+// enqueue the kernels of ONE step (wavenet.py:408-501 + sampler + queue pushes)
+void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, const float* forced,
+                     const float* enc, int Tn, int per_step, const float* rnd, uint64_t seed, int* idx,
+                     float* wav, float* out_params, hipStream_t st) {
+    const ArStateLayout L = ar_state_layout(h, B);
+    const ArDims D = ar_dims(h, B);
+    const ArPack& P = h->ar;
+    const float* blob = h->d_blob;
+    hipLaunchKernelGGL(ar_start_kernel, dim3((B * D.W + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
+                       forced, Tn, blob + P.start_off);
+    hipLaunchKernelGGL(ar_rows_kernel<0>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wss_off,
+                       blob + P.bss_off, D.S, D.W, enc, Tn, per_step, (size_t)0, 1);
+    for (const ArLayerPack& lp : P.layers) {
+        hipLaunchKernelGGL(ar_gate_kernel, dim3((D.G / 2 + 3) / 4), dim3(256), 0, st, state, L, D,
+                           blob + lp.wd_off, blob + lp.bd_off, enc, Tn, per_step, lp.ring_off, lp.dilation);
+        hipLaunchKernelGGL(ar_rows_kernel<1>, dim3((D.W + D.S + 3) / 4), dim3(256), 0, st, state, L, D,
+                           blob + lp.wrs_off, blob + lp.brs_off, D.W + D.S, D.G / 2, enc, Tn, per_step,
+                           lp.ring_off, lp.dilation);
+    }
+    hipLaunchKernelGGL(ar_rows_kernel<2>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo1_off,
+                       blob + P.bo1_off, D.S, D.S + D.Cd, enc, Tn, per_step, (size_t)0, 1);
+    hipLaunchKernelGGL(ar_rows_kernel<3>, dim3((D.OW + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo2_off,
+                       blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step, (size_t)0, 1);
+    hipLaunchKernelGGL(ar_sample_kernel, dim3(B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
+                       per_step, Tn, idx, wav, out_params);
+    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
+}
+
+struct ArGraphCache {
+    hipGraphExec_t exec_multi = nullptr, exec_one = nullptr;
+    hipGraph_t g_multi = nullptr, g_one = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+void ar_cache_free(ArGraphCache* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->exec_multi) (void)hipGraphExecDestroy(c->exec_multi);
+    if (c->exec_one) (void)hipGraphExecDestroy(c->exec_one);
+    if (c->g_multi) (void)hipGraphDestroy(c->g_multi);
+    if (c->g_one) (void)hipGraphDestroy(c->g_one);
+    delete c;
+}
+
+}  // namespace
+
+void wn_ar_release(wn_handle* h) {
+    ar_cache_free(reinterpret_cast<ArGraphCache*>(h->ar_graph_cache));
+    h->ar_graph_cache = nullptr;
+}
+
+// ---------------------------------------------------------------------------
+int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
+    const wn_config& c = h->cfg;
+    const int W = c.width, S = c.skip_width, G = c.gate_width, Cd = c.deconv_width, OW = c.out_width;
+    auto var = [&](const std::string& nme) -> const std::vector<float>& { return h->vars.at(nme).data; };
+    auto begin = [&]() { blob.resize(align_up(blob.size(), 64)); return blob.size(); };
+    ArPack& P = h->ar;
+    {
+        P.start_off = begin();
+        std::vector<float> Wst = wn_get_kernel(h, "conv_start", "W", false);      // [3][1][W]
+        blob.insert(blob.end(), Wst.begin(), Wst.end());
+        const auto& b = var("conv_start/biases");
+        blob.insert(blob.end(), b.begin(), b.end());
+    }
+    auto pack_T = [&](const std::vector<float>& Wsrc, int cin, int cout, float* dst, int ld, int col0) {
+        // HWIO [1,1,cin,cout] -> dst[o*ld + col0 + ci]
+        for (int ci = 0; ci < cin; ++ci)
+            for (int o = 0; o < cout; ++o) dst[(size_t)o * ld + col0 + ci] = Wsrc[(size_t)ci * cout + o];
+    };
+    {
+        P.wss_off = begin();
+        blob.resize(blob.size() + (size_t)S * W);
+        pack_T(wn_get_kernel(h, "skip_start", "W", false), W, S, blob.data() + P.wss_off, W, 0);
+        P.bss_off = begin();
+        const auto& b = var("skip_start/biases");
+        blob.insert(blob.end(), b.begin(), b.end());
+    }
+    size_t ring = 0;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string s = std::to_string(i + 1);
+        ArLayerPack lp;
+        lp.dilation = 1 << (i % c.num_stages);                                     // wavenet.py:453
+        lp.ring_off = ring;
+        ring += (size_t)2 * lp.dilation * W;
+        const int K = 3 * W + Cd;
+        std::vector<float> Wd = wn_get_kernel(h, "dilated_conv_" + s, "W", false);   // [3][W][G]
+        lp.wd_off = begin();
+        blob.resize(blob.size() + (size_t)G * K);
+        float* dst = blob.data() + lp.wd_off;
+        for (int tap = 0; tap < 3; ++tap)      // tap 0 <-> x[t-2d] (masked.py:369-371)
+            for (int ci = 0; ci < W; ++ci)
+                for (int o = 0; o < G; ++o)
+                    dst[(size_t)o * K + tap * W + ci] = Wd[((size_t)tap * W + ci) * G + o];
+        pack_T(wn_get_kernel(h, "mel_cond_" + s, "W", false), Cd, G, dst, K, 3 * W);
+        lp.bd_off = begin();
+        {
+            const auto& bd = var("dilated_conv_" + s + "/biases");
+            const auto& bc = var("mel_cond_" + s + "/biases");
+            for (int o = 0; o < G; ++o) blob.push_back(bd[o] + bc[o]);
+        }
+        lp.wrs_off = begin();
+        blob.resize(blob.size() + (size_t)(W + S) * (G / 2));
+        dst = blob.data() + lp.wrs_off;
+        pack_T(wn_get_kernel(h, "res_" + s, "W", false), G / 2, W, dst, G / 2, 0);
+        pack_T(wn_get_kernel(h, "skip_" + s, "W", false), G / 2, S, dst + (size_t)W * (G / 2), G / 2, 0);
+        lp.brs_off = begin();
+        {
+            const auto& br = var("res_" + s + "/biases");
+            const auto& bs = var("skip_" + s + "/biases");
+            blob.insert(blob.end(), br.begin(), br.end());
+            blob.insert(blob.end(), bs.begin(), bs.end());
+        }
+        P.layers.push_back(lp);
+    }
+    P.ring_floats = ring;
+    {
+        P.wo1_off = begin();
+        blob.resize(blob.size() + (size_t)S * (S + Cd));
+        float* dst = blob.data() + P.wo1_off;
+        pack_T(wn_get_kernel(h, "out1", "W", false), S, S, dst, S + Cd, 0);
+        pack_T(wn_get_kernel(h, "mel_cond_out1", "W", false), Cd, S, dst, S + Cd, S);
+        P.bo1_off = begin();
+        const auto& b1 = var("out1/biases");
+        const auto& b2 = var("mel_cond_out1/biases");
+        for (int o = 0; o < S; ++o) blob.push_back(b1[o] + b2[o]);
+        P.wo2_off = begin();
+        blob.resize(blob.size() + (size_t)OW * S);
+        pack_T(wn_get_kernel(h, "out2", "W", false), S, OW, blob.data() + P.wo2_off, S, 0);
+        P.bo2_off = begin();
+        const auto& b3 = var("out2/biases");
+        blob.insert(blob.end(), b3.begin(), b3.end());
+    }
+    return WN_OK;
+}
+
+extern "C" int wn_ar_n_rand(const wn_handle* h) {
+    if (!h || h->cfg.kind != WN_KIND_TEACHER) return WN_EINVAL;
+    return h->cfg.loss_type == WN_LOSS_MOL ? h->cfg.mol_mix + 1 : 1;
+}
+
+extern "C" size_t wn_ar_state_bytes(const wn_handle* h, int B) {
+    if (!h || h->cfg.kind != WN_KIND_TEACHER || !h->finalized || B < 1) return 0;
+    return align_up(ar_state_layout(h, B).total * sizeof(float), 256);
+}
+
+static int ar_check(wn_handle* h, const char* fn, int B) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "%s: null handle", fn);
+    if (!h->finalized) return wn_fail(h, WN_ESTATE, "%s: call wn_finalize first", fn);
+    if (h->cfg.kind != WN_KIND_TEACHER) return wn_fail(h, WN_EINVAL, "%s: handle is not a teacher Wavenet", fn);
+    if (B < 1) return wn_fail(h, WN_EINVAL, "%s: B must be >= 1", fn);
+    return WN_OK;
+}
+
+extern "C" int wn_ar_reset(wn_handle* h, void* state, int B, void* stream) {
+    int rc = ar_check(h, "wn_ar_reset", B);
+    if (rc) return rc;
+    if (!state) return wn_fail(h, WN_EINVAL, "wn_ar_reset: null state");
+    // masked.py:352-355: both queues of every causal layer start as `rate` zeros
+    WN_HIP(h, hipMemsetAsync(state, 0, wn_ar_state_bytes(h, B), reinterpret_cast<hipStream_t>(stream)));
+    return WN_OK;
+}
+
+extern "C" int wn_ar_step(wn_handle* h, void* state, int B, const float* wav_in, const float* enc_t,
+                          const float* rnd, uint64_t seed, int32_t* sample, float* out_params, void* stream) {
+    int rc = ar_check(h, "wn_ar_step", B);
+    if (rc) return rc;
+    if (!state || !wav_in || !enc_t || !sample) return wn_fail(h, WN_EINVAL, "wn_ar_step: null argument");
+    ar_enqueue_step(h, reinterpret_cast<float*>(state), B, wav_in, nullptr, enc_t, 1, 1, rnd, seed, sample,
+                    nullptr, out_params, reinterpret_cast<hipStream_t>(stream));
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
+extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, const float* rnd, uint64_t seed,
+                              int32_t* idx, float* wav, const float* forced_wav, float* out_params, void* ws,
+                              size_t ws_bytes, void* stream) {
+    int rc = ar_check(h, "wn_ar_generate", B);
+    if (rc) return rc;
+    if (Tn < 0) return wn_fail(h, WN_EINVAL, "wn_ar_generate: negative length");
+    if (Tn == 0) return WN_OK;
+    if (!enc || !ws || (!idx && !wav)) return wn_fail(h, WN_EINVAL, "wn_ar_generate: null argument");
+    const size_t need = wn_ar_state_bytes(h, B);
+    if (ws_bytes < need) return wn_fail(h, WN_ENOMEM, "wn_ar_generate: workspace %zu < %zu bytes", ws_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* state = reinterpret_cast<float*>(ws);
+    WN_HIP(h, hipMemsetAsync(state, 0, need, st));
+
+    if (!st) {
+        // the legacy null stream cannot be captured: plain launches
+        for (int t = 0; t < Tn; ++t)
+            ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
+        WN_HIP(h, hipGetLastError());
+        return WN_OK;
+    }
+    // Every per-step address is derived on the device from the step counter, so a
+    // captured step is static: build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay.
+    wn_ar_release(h);
+    ArGraphCache* gc = new ArGraphCache();
+    h->ar_graph_cache = gc;
+    gc->stream = st;
+    const int multi = Tn / AR_GRAPH_STEPS, rest = Tn % AR_GRAPH_STEPS;
+    if (multi) {
+        WN_HIP(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < AR_GRAPH_STEPS; ++i)
+            ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
+        WN_HIP(h, hipStreamEndCapture(st, &gc->g_multi));
+        WN_HIP(h, hipGraphInstantiate(&gc->exec_multi, gc->g_multi, nullptr, nullptr, 0));
+    }
+    if (rest) {
+        WN_HIP(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
+        WN_HIP(h, hipStreamEndCapture(st, &gc->g_one));
+        WN_HIP(h, hipGraphInstantiate(&gc->exec_one, gc->g_one, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < multi; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_multi, st));
+    for (int i = 0; i < rest; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_one, st));
+    return WN_OK;
+}
+
+size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F) {
+    const int64_t Tn = wn_ar_length(h, F);
+    const size_t dec = align_up((size_t)B * h->cfg.deconv_width * Tn * sizeof(float), 256) +
+                       wn_deconv_scratch_bytes(h, B, F);
+    const size_t ar = wn_ar_state_bytes(h, B);
+    return dec > ar ? dec : ar;
+}

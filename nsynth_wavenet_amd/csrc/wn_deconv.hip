@@ -1,0 +1,255 @@
+// Mel-conditioning upsampler: the transposed-conv stack
+//   wavenet/wavenet.py:46-73 (_deconv_stack), wavenet/masked.py:235-291 (trans_conv1d)
+// as fp32 MFMA GEMMs on gfx950.
+//
+// conv2d_transpose(SAME, stride S, filter [1,K,Cout,Cin]) in closed form:
+//   y[n,co] = bias[co] + sum_i sum_ci x[i,ci] * W[n + pL - i*S, co, ci],  pL = (K-S)/2.
+// With n + pL = S*q + r this is, per phase r, a dense GEMM over k = (j, ci):
+//   y[S*q + r - pL, co] = bias[co] + sum_{j<K/S} sum_ci W[S*j + r, co, ci] * x[q - j, ci]
+// so  A = W_r [Cout x (K/S*Cin)]  (weights, pre-packed in MFMA A-fragment order)
+//     B = X   [(j,ci) x q]        (activations, channel-major rows, time contiguous)
+//     D = Y_r [Cout x q]
+// Activations are kept CHANNEL-MAJOR ([C][time]) everywhere on the device so that
+// the B operand of v_mfma_f32_16x16x4_f32 (lane = (k>>?, n)) is a coalesced
+// time-contiguous load and dilation / tap shifts are plain column offsets.
+#include "wn_internal.h"
+
+
+namespace {
+
+constexpr int DC_NT = 4;             // 16-column MFMA tiles per wave (dwordx4 loads)
+constexpr int DC_QT = 16 * DC_NT;    // q columns per wave
+constexpr int DC_XOFF = 8;           // zero columns left of sample 0 in every input row
+
+__host__ __device__ inline int dc_row_stride(int L) {
+    // columns: [xoff zeros][L samples][zeros up to the rounded q range + slack]
+    return DC_XOFF + ((L + 2 + DC_QT - 1) / DC_QT) * DC_QT + 8;
+}
+
+// mel [B,F,C] (reference layout) -> channel-major padded rows [B][C][xs]
+__global__ void mel_to_cm_kernel(const float* __restrict__ mel, float* __restrict__ out,
+                                 int F, int C, int xs) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= xs) return;
+    const int f = col - DC_XOFF;
+    float v = 0.f;
+    if (f >= 0 && f < F) v = mel[((size_t)b * F + f) * C + c];
+    out[((size_t)b * C + c) * xs + col] = v;
+}
+
+__device__ inline float apply_act(float v, int act) {
+    if (act == WN_ACT_LEAKY_RELU) return fmaxf(v, 0.4f * v);   // masked.py:33-34
+    if (act == WN_ACT_RELU) return fmaxf(v, 0.f);
+    return tanhf(v);
+}
+
+// One workgroup = 4 waves; wave w owns output channels [64*(4*zc + w), +64) as 4
+// MFMA row blocks; all waves share the same 64 q columns (their B loads hit L1).
+__global__ __launch_bounds__(256) void deconv_mfma_kernel(
+    const float* __restrict__ x, int cin, int xs,
+    const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int cout, int64_t ys, int yoff,
+    int L, int S, int pL, int taps, int act, int zc_count) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int r = blockIdx.y;
+    const int b = blockIdx.z / zc_count, zc = blockIdx.z % zc_count;
+    const int cg = zc * 4 + wave;                 // 64-channel group
+    if (cg * 64 >= cout) return;
+    const int q0 = blockIdx.x * DC_QT;
+    const int nmb = cout / 16;
+    const int cblk = cin / 16;                    // K-step groups (of 4 K-steps) per tap
+    const int nks4 = taps * cblk;
+
+    f4 acc[4][DC_NT];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int e = 0; e < DC_NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const f4* wpr = reinterpret_cast<const f4*>(wp) + ((size_t)r * nks4 * nmb + cg * 4) * 64 + lane;
+    const float* xb = x + (size_t)b * cin * xs + DC_XOFF + q0 + DC_NT * n;
+
+    for (int j = 0; j < taps; ++j) {
+        for (int c4 = 0; c4 < cblk; ++c4) {
+            const int ks4 = j * cblk + c4;
+            f4 a[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = wpr[((size_t)ks4 * nmb + mb) * 64];
+            f4 bv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int ci = 16 * c4 + 4 * jj + kq;
+                bv[jj] = *reinterpret_cast<const f4u*>(xb + (size_t)ci * xs - j);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int e = 0; e < DC_NT; ++e)
+                        acc[mb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][jj], bv[jj][e], acc[mb][e], 0, 0, 0);
+        }
+    }
+
+    const int64_t SL = (int64_t)S * L;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = 64 * cg + 16 * mb + 4 * kq + rr;
+            const float bco = bias[co];
+            float* yr = y + ((size_t)b * cout + co) * ys + yoff;
+#pragma unroll
+            for (int e = 0; e < DC_NT; ++e) {
+                const int64_t nn = (int64_t)S * (q0 + DC_NT * n + e) + r - pL;
+                if (nn >= 0 && nn < SL) yr[nn] = apply_act(acc[mb][e][rr] + bco, act);
+            }
+        }
+}
+
+// channel-major [B][C][T] (row stride cs) -> reference layout [B][T][C]
+__global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                int C, int64_t T, int64_t cs) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const int64_t t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? in[((size_t)b * C + c) * cs + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t t = t0 + i;
+        const int c = c0 + tx;
+        if (t < T && c < C) out[((size_t)b * T + t) * C + c] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
+    const wn_config& c = h->cfg;
+    for (auto& sp : h->stacks) {
+        int cin = c.n_mel;
+        for (int j = 0; j < c.n_deconv; ++j) {
+            DeconvLayerPack lp;
+            lp.cin = cin;
+            lp.cout = c.deconv_width;
+            lp.K = c.deconv_filter[j];
+            lp.S = c.deconv_stride[j];
+            lp.pL = (lp.K - lp.S) / 2;
+            lp.taps = lp.K / lp.S;
+            if (cin % 16) return wn_fail(h, WN_EINVAL, "deconv: input channels %d not a multiple of 16", cin);
+            std::string scope = (sp.prefix.empty() ? std::string() : sp.prefix + "/") + "trans_conv_" +
+                                std::to_string(j + 1);
+            std::vector<float> W = wn_get_kernel(h, scope, "kernel", true);   // [K][cout][cin]
+            const std::vector<float>& bias = h->vars.at(scope + "/bias").data;
+            const int nmb = lp.cout / 16, cblk = cin / 16, nks4 = lp.taps * cblk;
+            blob.resize(align_up(blob.size(), 64));
+            lp.w_off = blob.size();
+            blob.resize(blob.size() + (size_t)lp.S * nks4 * nmb * 256);
+            float* P = blob.data() + lp.w_off;
+            for (int r = 0; r < lp.S; ++r)
+                for (int ks4 = 0; ks4 < nks4; ++ks4) {
+                    const int tap = ks4 / cblk, c4 = ks4 % cblk;
+                    for (int mb = 0; mb < nmb; ++mb)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int i = lane & 15, kq = lane >> 4;
+                                const int co = 16 * mb + i, ci = 16 * c4 + 4 * jj + kq;
+                                const int k = lp.S * tap + r;
+                                P[((((size_t)r * nks4 + ks4) * nmb + mb) * 64 + lane) * 4 + jj] =
+                                    W[((size_t)k * lp.cout + co) * cin + ci];
+                            }
+                }
+            lp.b_off = blob.size();
+            blob.insert(blob.end(), bias.begin(), bias.end());
+            sp.layers.push_back(lp);
+            cin = lp.cout;
+        }
+    }
+    return WN_OK;
+}
+
+// scratch: channel-major mel + every intermediate layer output
+size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F) {
+    const wn_config& c = h->cfg;
+    size_t fl = (size_t)B * c.n_mel * dc_row_stride(F);
+    int64_t L = F;
+    for (int j = 0; j + 1 < c.n_deconv; ++j) {
+        L *= c.deconv_stride[j];
+        fl += (size_t)B * c.deconv_width * dc_row_stride((int)L);
+    }
+    return align_up(fl * sizeof(float), 256);
+}
+
+int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* enc_cm,
+                  int64_t enc_stride, void* scratch, hipStream_t st) {
+    const wn_config& c = h->cfg;
+    const DeconvStackPack& sp = h->stacks[si];
+    float* buf = reinterpret_cast<float*>(scratch);
+    int xs = dc_row_stride(F);
+    {
+        dim3 g((xs + 255) / 256, c.n_mel, B);
+        hipLaunchKernelGGL(mel_to_cm_kernel, g, dim3(256), 0, st, mel, buf, F, c.n_mel, xs);
+    }
+    const float* x = buf;
+    float* next = buf + (size_t)B * c.n_mel * xs;
+    int L = F;
+    for (int j = 0; j < c.n_deconv; ++j) {
+        const DeconvLayerPack& lp = sp.layers[j];
+        const bool last = (j + 1 == c.n_deconv);
+        const int Lout = L * lp.S;
+        float* y;
+        int64_t ys;
+        int yoff;
+        if (last) {
+            y = enc_cm; ys = enc_stride; yoff = 0;
+        } else {
+            y = next; ys = dc_row_stride(Lout); yoff = DC_XOFF;
+            WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
+        }
+        const int Q = L + 2;
+        const int zc = (lp.cout + 255) / 256;
+        dim3 g((Q + DC_QT - 1) / DC_QT, lp.S, B * zc);
+        hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off,
+                           h->d_blob + lp.b_off, y, lp.cout, ys, yoff, L, lp.S, lp.pL, lp.taps,
+                           c.upsample_act, zc);
+        x = y;
+        xs = (int)ys;
+        next = y + (size_t)B * lp.cout * ys;
+        L = Lout;
+    }
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
+extern "C" int wn_deconv(wn_handle* h, const char* scope, const float* mel, int B, int F, float* enc,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_deconv: null handle");
+    if (!h->finalized) return wn_fail(h, WN_ESTATE, "wn_deconv: call wn_finalize first");
+    if (!mel || !enc || !ws || B < 1 || F < 1) return wn_fail(h, WN_EINVAL, "wn_deconv: bad argument");
+    int si = -1;
+    for (size_t i = 0; i < h->stacks.size(); ++i)
+        if (h->stacks[i].prefix == (scope ? scope : "")) si = (int)i;
+    if (si < 0) return wn_fail(h, WN_ENOENT, "wn_deconv: no deconv stack with scope '%s'", scope ? scope : "");
+    const int64_t Tn = (int64_t)F * h->frame_shift;
+    const size_t cm_bytes = align_up((size_t)B * h->cfg.deconv_width * Tn * sizeof(float), 256);
+    const size_t need = cm_bytes + wn_deconv_scratch_bytes(h, B, F);
+    if (ws_bytes < need)
+        return wn_fail(h, WN_ENOMEM, "wn_deconv: workspace %zu < %zu bytes", ws_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* cm = reinterpret_cast<float*>(ws);
+    int rc = wn_run_deconv(h, si, mel, B, F, cm, Tn, reinterpret_cast<char*>(ws) + cm_bytes, st);
+    if (rc) return rc;
+    dim3 g((unsigned)((Tn + 31) / 32), (h->cfg.deconv_width + 31) / 32, B);
+    hipLaunchKernelGGL(cm_to_tm_kernel, g, dim3(256), 0, st, cm, enc, h->cfg.deconv_width, Tn, Tn);
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}

@@ -1,0 +1,583 @@
+// Parallel-WaveNet (IAF) student generation on gfx950:
+//   wavenet/parallel_wavenet.py:200-287 (_create_iaf), :289-345 (feed_forward),
+//   :347-359 (_clip_quant_scale), :172-184 (noise sources).
+//
+// Device data layout (all fp32, caller-provided workspace):
+//   l   ping/pong  [B][64][LP + T]   residual stream, CHANNEL-MAJOR rows, LP zero
+//                                    columns on the left so t-d / t-2d never branch
+//   enc            [B][256][TE]      upsampled mel (wn_deconv.hip), channel-major
+//   x              [B][XP + T]       flow input/output, XP zero columns on the left
+//   x0, M, S       [B][T]            noise, mean_tot, scale_tot
+//
+// One residual layer (parallel_wavenet.py:227-254) is ONE kernel:
+//   h[o,t]  = bd+bc + sum_k Wd[tap k] l[:, t-(2-k)d] + Wc enc[:, t+c0]     (K = 448)
+//   g[c,t]  = sigmoid(h[c,t]) * tanh(h[c+32,t])
+//   l'[o,t] = l[o,t] + br + Wr g[:, t]                                       (K = 32)
+// as v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand (M = output channel)
+// and the ACTIVATIONS as the B operand (N = time).  With that orientation
+//   * B-operand loads are time-contiguous (coalesced) rows, dilation is a column
+//     offset, the centre crop (wavenet.py:76-85) is a pointer offset;
+//   * the accumulator holds, per lane, one time step and channels {16mb+4q+r}:
+//     sigmoid channel c and tanh channel c+32 sit in the same lane and register
+//     index (row blocks mb and mb+2), so the gate is lane-local;
+//   * the gated registers ARE the B operand of the residual 1x1 (K order is
+//     chosen to match the accumulator layout), and the tap-t loads ARE its C-in.
+// Weights are packed on the host in A-fragment order and staged once per
+// workgroup in LDS (120.5 KB); workgroups are persistent over 64-sample tiles.
+#include "wn_internal.h"
+#include "wn_codec.h"
+
+namespace {
+
+constexpr float EXP_M9 = 1.2340980408667956e-4f;
+constexpr float EXP_7 = 1096.6331584284585f;
+
+__device__ inline f4 mfma4(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ inline float sigmoidf_(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
+__device__ inline float tanhf_(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * a) + 1.f); }
+
+// ---------------- noise (parallel_wavenet.py:172-184) ----------------
+// 4 samples per thread.  logistic: log u - log(1-u), u ~ U(1e-5, 1-1e-5); gauss: Box-Muller.
+__global__ void iaf_noise_kernel(float* __restrict__ x0, float* __restrict__ x, int64_t T, int XR,
+                                 uint64_t seed, int gauss) {
+    const int b = blockIdx.y;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= T) return;
+    uint32_t c[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)b, 0x49414630u};
+    wn_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float v[4];
+    if (!gauss) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u01 = (float)(c[e] >> 8) * (1.0f / 16777216.0f);
+            const float u = u01 * (1.f - 2e-5f) + 1e-5f;
+            v[e] = logf(u) - logf(1.f - u);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const float u1 = ((float)(c[e] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+            const float u2 = (float)(c[e + 1] >> 8) * (1.0f / 16777216.0f);
+            const float rr = sqrtf(-2.f * logf(u1));
+            v[e] = rr * cosf(6.283185307179586f * u2);
+            v[e + 1] = rr * sinf(6.283185307179586f * u2);
+        }
+    }
+    *reinterpret_cast<f4*>(x0 + (size_t)b * T + i4 * 4) = (f4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f4*>(x + (size_t)b * XR + IAF_XP + i4 * 4) = (f4){v[0], v[1], v[2], v[3]};
+}
+
+__global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __restrict__ x, int64_t T, int XR) {
+    const int b = blockIdx.y;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= T) return;
+    *reinterpret_cast<f4*>(x + (size_t)b * XR + IAF_XP + i4 * 4) =
+        *reinterpret_cast<const f4*>(noise + (size_t)b * T + i4 * 4);
+}
+
+// zero the left pads of `rows` rows (row stride rs floats, pad floats each)
+__global__ void zero_pad_kernel(float* __restrict__ p, int64_t rs, int pad, int rows) {
+    const int row = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
+}
+
+// ---------------- start conv (parallel_wavenet.py:222-225; masked.py:39-52) ----------------
+// l[c,t] = b[c] + W0[c] x[t-3] + W1[c] x[t-2] + W2[c] x[t-1]   (shift_right folded into the taps)
+__global__ void iaf_start_kernel(const float* __restrict__ x, const float* __restrict__ wb,
+                                 float* __restrict__ l, int64_t T, int XR, int64_t RS) {
+    const int b = blockIdx.y;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t >= T) return;
+    const float* xp = x + (size_t)b * XR + IAF_XP + t;
+    float xv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xv[i] = xp[i - 3];
+    float* lp = l + (size_t)b * IAF_W * RS + IAF_LP + t;
+    for (int c = 0; c < IAF_W; ++c) {
+        const float w0 = wb[c], w1 = wb[IAF_W + c], w2 = wb[2 * IAF_W + c], bb = wb[3 * IAF_W + c];
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = bb + w0 * xv[e] + w1 * xv[e + 1] + w2 * xv[e + 2];
+        *reinterpret_cast<f4*>(lp + (size_t)c * RS) = o;
+    }
+}
+
+// ---------------- fused residual layer ----------------
+__global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
+    const float* __restrict__ lin, float* __restrict__ lout, const float* __restrict__ enc,
+    const float* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f4* src = reinterpret_cast<const f4*>(wpack);
+        f4* dst = reinterpret_cast<f4*>(lds);
+        for (int i = threadIdx.x; i < IAF_LAYER_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
+    const f4* PRl = Pl + IAF_P_FLOATS / 4;
+    const float* bg = lds + IAF_P_FLOATS + IAF_PR_FLOATS + q * 16;
+    const float* br = bg + 64;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row;
+        const int t0 = (tile - b * tiles_per_row) * 64 + wave * 16;
+        const float* lrow = lin + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
+        const float* erow = enc + (size_t)b * IAF_CD * TE + t0 + n;
+
+        f4 acc[4], cur[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bg + mb * 4);
+
+        // 28 K-groups of 4 K-steps (16 MFMAs each): groups 0-11 = the three causal taps
+        // t-2d, t-d, t of the dilated conv (4 groups of 16 channels each), groups 12-27 =
+        // the conditioning 1x1 over the 256 upsampled-mel channels.  Software pipeline:
+        // weights (A) are read from LDS one group ahead, activations (B) from global two
+        // groups ahead, so the f32 MFMA pipe (32 cycles/instruction) never waits on memory.
+        auto loadA = [&](int g, f4 (&a)[4]) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = Pl[(g * 4 + mb) * 64];
+        };
+        auto loadB = [&](int g) -> f4 {
+            const float* p;
+            int64_t stride;
+            if (g < 12) {
+                p = lrow + (int64_t)(16 * (g & 3) + 4 * q) * RS - (2 - (g >> 2)) * d;
+                stride = RS;
+            } else {
+                p = erow + (int64_t)(16 * (g - 12) + 4 * q) * TE;
+                stride = TE;
+            }
+            return (f4){p[0], p[stride], p[2 * stride], p[3 * stride]};
+        };
+        f4 a1[4], b1, b2;
+        loadA(0, a1);
+        b1 = loadB(0);
+        b2 = loadB(1);
+        auto group = [&](int g) -> f4 {
+            f4 a0[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a0[mb] = a1[mb];
+            const f4 b0 = b1;
+            b1 = b2;
+            if (g + 1 < 28) loadA(g + 1, a1);
+            if (g + 2 < 28) b2 = loadB(g + 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a0[mb][jj], b0[jj], acc[mb]);
+            return b0;
+        };
+#pragma unroll 1
+        for (int g = 0; g < 8; ++g) group(g);
+#pragma unroll
+        for (int g = 8; g < 12; ++g) cur[g - 8] = group(g);     // tap t: also the residual C-in
+#pragma unroll 1
+        for (int g = 12; g < 28; ++g) group(g);
+        // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
+        f4 g[2];
+#pragma unroll
+        for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[mg][r] = sigmoidf_(acc[mg][r]) * tanhf_(acc[mg + 2][r]);
+        // residual 1x1, accumulated onto l
+        f4 d2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) d2[mb] = cur[mb] + *reinterpret_cast<const f4*>(br + mb * 4);
+#pragma unroll
+        for (int j4 = 0; j4 < 2; ++j4) {
+            f4 a[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = PRl[(j4 * 4 + mb) * 64];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) d2[mb] = mfma4(a[mb][jj], g[j4][jj], d2[mb]);
+        }
+        float* orow = lout + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orow[(size_t)(16 * mb + 4 * q + r) * RS] = d2[mb][r];
+    }
+}
+
+// ---------------- flow head (parallel_wavenet.py:256-277, :319-324) ----------------
+__device__ inline float softplus_tf(float p) {
+    // tf.nn.softplus (Eigen): threshold = log(eps) + 2
+    const float thr = -13.942384719848633f;
+    if (p > -thr) return p;
+    if (p < thr) return expf(p);
+    return log1pf(expf(p));
+}
+
+__global__ __launch_bounds__(256, 1) void iaf_head_kernel(
+    const float* __restrict__ lin, const float* __restrict__ enc, const float* __restrict__ wpack,
+    float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
+    int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f4* src = reinterpret_cast<const f4*>(wpack);
+        f4* dst = reinterpret_cast<f4*>(lds);
+        for (int i = threadIdx.x; i < IAF_HEAD_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
+    const float* bo = lds + IAF_PH_FLOATS + q * 16;
+    const float* wm = bo + 64;
+    const float* wsc = wm + 64;
+    const float bmean = lds[IAF_PH_FLOATS + 192], bscale = lds[IAF_PH_FLOATS + 193];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row;
+        const int t0 = (tile - b * tiles_per_row) * 64 + wave * 16;
+        const float* lrow = lin + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
+        const float* erow = enc + (size_t)b * IAF_CD * TE + t0 + n;
+        f4 acc[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bo + mb * 4);
+        // 20 K-groups: 0-3 = out1 over relu(l), 4-19 = mel_cond_out1 over the 256 enc channels
+        auto loadA = [&](int g, f4 (&a)[4]) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = Pl[(g * 4 + mb) * 64];
+        };
+        auto loadB = [&](int g) -> f4 {
+            if (g < 4) {
+                const float* p = lrow + (int64_t)(16 * g + 4 * q) * RS;
+                return (f4){fmaxf(p[0], 0.f), fmaxf(p[RS], 0.f), fmaxf(p[2 * RS], 0.f), fmaxf(p[3 * RS], 0.f)};
+            }
+            const float* p = erow + (int64_t)(16 * (g - 4) + 4 * q) * TE;
+            return (f4){p[0], p[TE], p[2 * TE], p[3 * TE]};
+        };
+        f4 a1[4], b1, b2;
+        loadA(0, a1);
+        b1 = loadB(0);
+        b2 = loadB(1);
+#pragma unroll 1
+        for (int g = 0; g < 20; ++g) {
+            f4 a0[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a0[mb] = a1[mb];
+            const f4 b0 = b1;
+            b1 = b2;
+            if (g + 1 < 20) loadA(g + 1, a1);
+            if (g + 2 < 20) b2 = loadB(g + 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a0[mb][jj], b0[jj], acc[mb]);
+        }
+        float pm = 0.f, ps = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o = fmaxf(acc[mb][r], 0.f);
+                pm = fmaf(wm[mb * 4 + r], o, pm);
+                ps = fmaf(wsc[mb * 4 + r], o, ps);
+            }
+        pm += __shfl_xor(pm, 16);
+        ps += __shfl_xor(ps, 16);
+        pm += __shfl_xor(pm, 32);
+        ps += __shfl_xor(ps, 32);
+        if (q == 0) {
+            const int64_t t = t0 + n;
+            const float mean = pm + bmean;
+            const float s = fminf(fmaxf(softplus_tf(ps + bscale), EXP_M9), EXP_7);   // :105-114
+            float* xp = x + (size_t)b * XR + IAF_XP + t;
+            *xp = *xp * s + mean;                                                    // :277
+            float* mp = Mt + (size_t)b * T + t;
+            float* sp = St + (size_t)b * T + t;
+            if (first) { *mp = mean; *sp = s; }
+            else { *mp = mean + *mp * s; *sp = *sp * s; }                            // :322-323
+        }
+    }
+}
+
+// ---------------- final affine + _clip_quant_scale (parallel_wavenet.py:326-330,347-359) ----------------
+__device__ inline void clip_quant_one(float y, int Q, int mu, float& wav, int& qi) {
+    qi = wn_clip_quantize(y, Q);
+    wav = wn_dequant(qi, Q, mu);
+}
+
+__global__ void iaf_final_kernel(const float* __restrict__ x0, const float* __restrict__ Mt,
+                                 const float* __restrict__ St, int64_t n, int Q, int mu,
+                                 float* __restrict__ wav, int* __restrict__ idx, float* __restrict__ xraw,
+                                 float* __restrict__ mean_tot, float* __restrict__ scale_tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = fminf(St[i], EXP_7);                    // :327
+    const float m = Mt[i];
+    const float y = x0[i] * s + m;                          // :330
+    float w; int qi;
+    clip_quant_one(y, Q, mu, w, qi);
+    wav[i] = w;
+    if (idx) idx[i] = qi;
+    if (xraw) xraw[i] = y;
+    if (mean_tot) mean_tot[i] = m;
+    if (scale_tot) scale_tot[i] = s;
+}
+
+__global__ void clip_quant_kernel(const float* __restrict__ x, int64_t n, int Q, int mu,
+                                  float* __restrict__ wav, int* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float w; int qi;
+    clip_quant_one(x[i], Q, mu, w, qi);
+    if (wav) wav[i] = w;
+    if (idx) idx[i] = qi;
+}
+
+struct IafLayout {
+    int64_t T, TE, RS;
+    int XR, c0;
+    size_t enc, lA, lB, x, x0, M, S, scratch, total;   // byte offsets
+};
+
+IafLayout iaf_layout(const wn_handle* h, int B, int F) {
+    IafLayout L;
+    L.T = wn_iaf_length(h, F);
+    L.TE = (int64_t)F * h->frame_shift;
+    L.c0 = (int)((L.TE - L.T) / 2);                        // wavenet.py:76-85
+    L.RS = IAF_LP + L.T;
+    L.XR = (int)(IAF_XP + L.T);
+    size_t o = 0;
+    auto carve = [&](size_t floats) { size_t r = o; o += align_up(floats * sizeof(float), 256); return r; };
+    L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
+    L.lA = carve((size_t)B * IAF_W * L.RS);
+    L.lB = carve((size_t)B * IAF_W * L.RS);
+    L.x = carve((size_t)B * L.XR);
+    L.x0 = carve((size_t)B * L.T);
+    L.M = carve((size_t)B * L.T);
+    L.S = carve((size_t)B * L.T);
+    L.scratch = o;
+    o += wn_deconv_scratch_bytes(h, B, F);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
+    const wn_config& c = h->cfg;
+    auto var = [&](const std::string& nme) -> const std::vector<float>& { return h->vars.at(nme).data; };
+    for (int k = 0; k < c.n_flows; ++k) {
+        const std::string p = "iaf_" + std::to_string(k + 1);
+        IafFlowPack fp;
+        fp.deconv_stack = c.share_deconv ? 0 : k;
+        // start conv: W [1,3,1,64] -> w[tap][c], then bias
+        blob.resize(align_up(blob.size(), 64));
+        fp.start_off = blob.size();
+        {
+            std::vector<float> W = wn_get_kernel(h, p + "/start_conv", "W", false);
+            blob.insert(blob.end(), W.begin(), W.end());
+            const auto& b = var(p + "/start_conv/biases");
+            blob.insert(blob.end(), b.begin(), b.end());
+        }
+        for (int i = 0; i < c.iaf_layers[k]; ++i) {
+            const std::string s = std::to_string(i + 1);
+            std::vector<float> Wd = wn_get_kernel(h, p + "/dilated_conv_" + s, "W", false);   // [3][64][64]
+            std::vector<float> Wc = wn_get_kernel(h, p + "/mel_cond_" + s, "W", false);       // [256][64]
+            std::vector<float> Wr = wn_get_kernel(h, p + "/res_" + s, "W", false);            // [32][64]
+            const auto& bd = var(p + "/dilated_conv_" + s + "/biases");
+            const auto& bc = var(p + "/mel_cond_" + s + "/biases");
+            const auto& br = var(p + "/res_" + s + "/biases");
+            IafLayerPack lp;
+            lp.dilation = 1 << (i % c.num_stages);          // parallel_wavenet.py:228
+            blob.resize(align_up(blob.size(), 64));
+            lp.off = blob.size();
+            blob.resize(blob.size() + IAF_LAYER_FLOATS);
+            float* P = blob.data() + lp.off;
+            float* PR = P + IAF_P_FLOATS;
+            float* bg = PR + IAF_PR_FLOATS;
+            float* brp = bg + 64;
+            for (int ks = 0; ks < 112; ++ks) {
+                const int seg = ks / 16, j = ks % 16;
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i16 = lane & 15, q = lane >> 4;
+                        const int o = 16 * mb + i16;
+                        const int kch = 16 * (j >> 2) + 4 * q + (j & 3);
+                        const float v = seg < 3 ? Wd[((size_t)seg * 64 + kch) * 64 + o]
+                                                : Wc[((size_t)(seg - 3) * 64 + kch) * 64 + o];
+                        P[((((ks >> 2) * 4 + mb) * 64) + lane) * 4 + (ks & 3)] = v;
+                    }
+            }
+            for (int j = 0; j < 8; ++j)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i16 = lane & 15, q = lane >> 4;
+                        const int o = 16 * mb + i16;
+                        const int cch = 16 * (j >> 2) + 4 * q + (j & 3);
+                        PR[((((j >> 2) * 4 + mb) * 64) + lane) * 4 + (j & 3)] = Wr[(size_t)cch * 64 + o];
+                    }
+            for (int q = 0; q < 4; ++q)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * mb + 4 * q + r;
+                        bg[q * 16 + mb * 4 + r] = bd[o] + bc[o];
+                        brp[q * 16 + mb * 4 + r] = br[o];
+                    }
+            fp.layers.push_back(lp);
+        }
+        // head
+        {
+            std::vector<float> Wo = wn_get_kernel(h, p + "/out1", "W", false);            // [64][64]
+            std::vector<float> Wco = wn_get_kernel(h, p + "/mel_cond_out1", "W", false);  // [256][64]
+            std::vector<float> Wm = wn_get_kernel(h, p + "/out2_mean", "W", false);       // [64][1]
+            std::vector<float> Ws = wn_get_kernel(h, p + "/out2_scale", "W", false);
+            const auto& bo = var(p + "/out1/biases");
+            const auto& bco = var(p + "/mel_cond_out1/biases");
+            blob.resize(align_up(blob.size(), 64));
+            fp.head_off = blob.size();
+            blob.resize(blob.size() + IAF_HEAD_FLOATS);
+            float* P = blob.data() + fp.head_off;
+            float* tb = P + IAF_PH_FLOATS;
+            for (int ks = 0; ks < 80; ++ks) {
+                const int seg = ks / 16, j = ks % 16;
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i16 = lane & 15, q = lane >> 4;
+                        const int o = 16 * mb + i16;
+                        const int kch = 16 * (j >> 2) + 4 * q + (j & 3);
+                        const float v = seg == 0 ? Wo[(size_t)kch * 64 + o]
+                                                 : Wco[((size_t)(seg - 1) * 64 + kch) * 64 + o];
+                        P[((((ks >> 2) * 4 + mb) * 64) + lane) * 4 + (ks & 3)] = v;
+                    }
+            }
+            for (int q = 0; q < 4; ++q)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * mb + 4 * q + r;
+                        tb[q * 16 + mb * 4 + r] = bo[o] + bco[o];
+                        tb[64 + q * 16 + mb * 4 + r] = Wm[o];
+                        tb[128 + q * 16 + mb * 4 + r] = Ws[o];
+                    }
+            tb[192] = var(p + "/out2_mean/biases")[0];
+            tb[193] = var(p + "/out2_scale/biases")[0];
+            tb[194] = tb[195] = 0.f;
+        }
+        h->flows.push_back(fp);
+    }
+    return WN_OK;
+}
+
+extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, const float* noise,
+                               uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
+                               float* scale_tot, float* rand_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_iaf_generate: null handle");
+    if (!h->finalized) return wn_fail(h, WN_ESTATE, "wn_iaf_generate: call wn_finalize first");
+    if (h->cfg.kind != WN_KIND_STUDENT)
+        return wn_fail(h, WN_EINVAL, "wn_iaf_generate: handle is not a ParallelWavenet student");
+    if (B < 1 || F < 1) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: B and F must be >= 1");
+    const IafLayout L = iaf_layout(h, B, F);
+    if (L.T == 0) return WN_OK;   // fewer frames than one max-dilation block: empty output
+    if (!mel || !wav || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: null mel/wav/workspace");
+    if (ws_bytes < L.total)
+        return wn_fail(h, WN_ENOMEM, "wn_iaf_generate: workspace %zu < %zu bytes", ws_bytes, L.total);
+    if ((int64_t)B * L.T / 64 > 0x7fffffff) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: batch too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = reinterpret_cast<char*>(ws);
+    float* enc = reinterpret_cast<float*>(base + L.enc);
+    float* lA = reinterpret_cast<float*>(base + L.lA);
+    float* lB = reinterpret_cast<float*>(base + L.lB);
+    float* x = reinterpret_cast<float*>(base + L.x);
+    float* x0g = reinterpret_cast<float*>(base + L.x0);
+    float* Mt = reinterpret_cast<float*>(base + L.M);
+    float* St = reinterpret_cast<float*>(base + L.S);
+    void* scratch = base + L.scratch;
+    const wn_config& c = h->cfg;
+
+    static bool attr_done = false;
+    if (!attr_done) {
+        WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      IAF_LAYER_FLOATS * sizeof(float)));
+        WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      IAF_HEAD_FLOATS * sizeof(float)));
+        attr_done = true;
+    }
+
+    // zero left pads
+    {
+        dim3 g((IAF_LP + 255) / 256, B * IAF_W);
+        hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lA, L.RS, IAF_LP, B * IAF_W);
+        hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lB, L.RS, IAF_LP, B * IAF_W);
+        hipLaunchKernelGGL(zero_pad_kernel, dim3(1, B), dim3(256), 0, st, x, (int64_t)L.XR, IAF_XP, B);
+    }
+    // noise
+    const float* x0 = noise;
+    {
+        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+        if (noise) {
+            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
+        } else {
+            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
+                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
+            x0 = x0g;
+        }
+    }
+    if (c.share_deconv) {
+        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st);
+        if (rc) return rc;
+    }
+    const int tiles_per_row = (int)(L.T / 64);
+    const int ntiles = B * tiles_per_row;
+    const int grid = ntiles < h->num_cu ? ntiles : h->num_cu;
+    const float* encc = enc + L.c0;
+    for (int k = 0; k < c.n_flows; ++k) {
+        const IafFlowPack& fp = h->flows[k];
+        if (!c.share_deconv) {
+            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st);
+            if (rc) return rc;
+        }
+        {
+            dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+            hipLaunchKernelGGL(iaf_start_kernel, g, dim3(256), 0, st, x, h->d_blob + fp.start_off, lA, L.T,
+                               L.XR, L.RS);
+        }
+        float* lin = lA;
+        float* lout = lB;
+        for (const IafLayerPack& lp : fp.layers) {
+            hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
+                               lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
+                               ntiles);
+            float* t = lin; lin = lout; lout = t;
+        }
+        hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
+                           encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
+                           tiles_per_row, ntiles);
+    }
+    {
+        const int64_t nn = (int64_t)B * L.T;
+        const int Q = c.use_mu_law ? 256 : 65536;
+        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
+                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
+        if (rand_out && rand_out != x0)
+            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
+extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav, int32_t* idx, void* stream) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_clip_quant: null handle");
+    if (n < 0 || (n > 0 && !x)) return wn_fail(h, WN_EINVAL, "wn_clip_quant: bad argument");
+    if (n == 0) return WN_OK;
+    const int Q = h->cfg.use_mu_law ? 256 : 65536;
+    hipLaunchKernelGGL(clip_quant_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, n, Q, h->cfg.use_mu_law, wav, idx);
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
+size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F) { return iaf_layout(h, B, F).total; }

@@ -1,0 +1,128 @@
+// Internal declarations shared by the translation units of libwnhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "wnhip.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+// 16-byte vector that is only 4-byte aligned: dilated taps / centre crops shift
+// time-contiguous rows by an arbitrary number of samples.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+};
+
+// ---- device-side parameter blocks (offsets in floats into wn_handle::d_blob) ----
+
+// One transposed-conv layer packed for the MFMA kernel (wn_deconv.hip).
+struct DeconvLayerPack {
+    int cin, cout, K, S, pL, taps;     // taps = K / S
+    size_t w_off;                      // packed A fragments [S][ks4][mb][64][4]
+    size_t b_off;                      // bias [cout]
+};
+
+struct DeconvStackPack {
+    std::string prefix;                // "", "iaf_share", "iaf_k"
+    std::vector<DeconvLayerPack> layers;
+};
+
+// Student flow (wn_iaf.hip)
+struct IafLayerPack {
+    size_t off;                        // LAYER_FLOATS floats: P | PR | bgate | bres
+    int dilation;
+};
+struct IafFlowPack {
+    size_t start_off;                  // w[3][W] | b[W]
+    std::vector<IafLayerPack> layers;
+    size_t head_off;                   // HEAD_FLOATS floats
+    int deconv_stack;                  // index into wn_handle::stacks
+};
+
+// Teacher (wn_ar.hip): plain [out][in] row-major matrices
+struct ArLayerPack {
+    size_t wd_off;    // [gate][3*width + deconv_width]   (taps t-2d, t-d, t, cond)
+    size_t bd_off;    // [gate]  (dilated bias + cond bias)
+    size_t wrs_off;   // [width + skip][gate/2]            (res rows then skip rows)
+    size_t brs_off;   // [width + skip]
+    int dilation;
+    size_t ring_off;  // float offset of this layer's ring inside the state (per batch elem)
+};
+struct ArPack {
+    size_t start_off;     // w[3][width] | b[width]
+    size_t wss_off, bss_off;   // skip_start [skip][width], [skip]
+    std::vector<ArLayerPack> layers;
+    size_t wo1_off, bo1_off;   // [skip][skip + deconv_width], [skip] (out1 | mel_cond_out1)
+    size_t wo2_off, bo2_off;   // [out_width][skip], [out_width]
+    size_t ring_floats;        // per batch element
+};
+
+struct wn_handle {
+    wn_config cfg;
+    std::map<std::string, HostTensor> vars;   // expected variables (+ data once set)
+    bool finalized = false;
+    int device = 0;
+    float* d_blob = nullptr;
+    size_t blob_floats = 0;
+    std::vector<DeconvStackPack> stacks;
+    std::vector<IafFlowPack> flows;
+    ArPack ar;
+    int frame_shift = 1;
+    int num_cu = 256;
+    mutable std::string err;
+    // cached hipGraph for the AR step (wn_ar.hip)
+    void* ar_graph_cache = nullptr;
+};
+
+// ---- error helpers ----
+int wn_fail(const wn_handle* h, int code, const char* fmt, ...);
+#define WN_HIP(h, expr)                                                              \
+    do {                                                                             \
+        hipError_t e__ = (expr);                                                     \
+        if (e__ != hipSuccess)                                                       \
+            return wn_fail((h), WN_EIO, "%s failed: %s (%s:%d)", #expr,              \
+                           hipGetErrorString(e__), __FILE__, __LINE__);              \
+    } while (0)
+
+// ---- sizes of the IAF packs (width 64, deconv_width 256) ----
+// layer: P 112 K-steps * 4 mb * 64 lanes | PR 8 * 4 * 64 | bgate 64 | bres 64
+constexpr int IAF_W = 64;
+constexpr int IAF_CD = 256;
+constexpr int IAF_P_FLOATS = 112 * 4 * 64;       // 28672
+constexpr int IAF_PR_FLOATS = 8 * 4 * 64;        // 2048
+constexpr int IAF_LAYER_FLOATS = IAF_P_FLOATS + IAF_PR_FLOATS + 64 + 64;   // 30848
+// head: PH 80 K-steps * 4 * 64 | bias 64 | wmean 64 | wscale 64 | bmean, bscale, pad
+constexpr int IAF_PH_FLOATS = 80 * 4 * 64;       // 20480
+constexpr int IAF_HEAD_FLOATS = IAF_PH_FLOATS + 64 * 3 + 4;                 // 20676
+
+constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
+constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
+
+// ---- implemented in the .hip units ----
+int wn_pack_deconv(wn_handle* h, std::vector<float>& blob);
+int wn_pack_iaf(wn_handle* h, std::vector<float>& blob);
+int wn_pack_ar(wn_handle* h, std::vector<float>& blob);
+
+// Runs stack `si` on mel [B,F,n_mel]; writes channel-major enc [B][cout][enc_stride]
+// (first valid sample at column 0).  Scratch carved from ws.
+struct DeconvScratch {
+    size_t bytes;
+};
+size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F);
+int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
+                  float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st);
+
+std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
+size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
+size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);
+void wn_ar_release(wn_handle* h);
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

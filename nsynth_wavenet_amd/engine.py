@@ -1,0 +1,205 @@
+"""Engine: one model on one GPU behind the C ABI (include/wnhip.h).
+
+PyTorch-ROCm is used only for device memory, streams and (in dist.py)
+torch.distributed; every arithmetic operation of the generation path runs in the
+hand-written HIP kernels of libwnhip.so.  There is no CPU or eager fallback: a
+missing library or a missing GPU raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import config as cfg
+from . import weights as wts
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Engine(object):
+    """Replaces one TF graph + Session of the reference (parallelgen.py:24-41,
+    fastgen.py:139-150): built from hparams, filled with named weights."""
+
+    def __init__(self, hparams, kind=None, device=None, n_mel=80):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('nsynth_wavenet_amd needs a ROCm GPU: the generation path has no CPU fallback')
+        self.hp = cfg.load_hparams(hparams)
+        self.kind = kind or cfg.model_kind(self.hp)
+        self.device = torch.device(device if device is not None else 'cuda:{}'.format(torch.cuda.current_device()))
+        self.n_mel = n_mel
+        self._h = ctypes.c_void_p(0)
+        self._ws = None
+        self._finalized = False
+        c = cfg.to_wn_config(self.hp, self.kind, n_mel)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.wn_create(ctypes.byref(c), ctypes.byref(self._h)))
+        self.quant_chann = cfg.quant_chann(self.hp)
+        self.frame_shift = cfg.frame_shift(self.hp)
+
+    # ---- lifecycle ----
+    def close(self):
+        if self._h:
+            torch.cuda.synchronize(self.device)
+            self.lib.wn_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        _lib.check(rc, self._h)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights ----
+    def set_weight(self, name, array):
+        a = np.ascontiguousarray(np.asarray(array, np.float32))
+        shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+        self._check(self.lib.wn_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                           shape, a.ndim))
+
+    def load_weights(self, weights):
+        """weights: dict TF-variable-name -> ndarray (see weights.expected_variables)."""
+        for name, _ in wts.expected_variables(self.hp, self.kind, self.n_mel):
+            if name not in weights:
+                raise KeyError('missing variable {}'.format(name))
+            self.set_weight(name, weights[name])
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_finalize(self._h))
+        self._finalized = True
+        return self
+
+    def load_checkpoint(self, path):
+        return self.load_weights(wts.load_checkpoint(path, self.hp, self.kind))
+
+    # ---- helpers ----
+    def iaf_length(self, F):
+        return int(self.lib.wn_iaf_length(self._h, int(F)))
+
+    def ar_length(self, F):
+        return int(self.lib.wn_ar_length(self._h, int(F)))
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev(self, x, dtype=torch.float32):
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+
+    # ---- IAF path ----
+    def iaf_generate(self, mel, noise=None, seed=0, want=('wav',)):
+        """ParallelWavenet.feed_forward + _clip_quant_scale.  mel [B,F,n_mel].
+        Returns a dict of device tensors for the names in `want` out of
+        wav, idx, x, mean_tot, scale_tot, rand_input."""
+        mel = self._dev(mel)
+        if mel.dim() != 3 or mel.shape[2] != self.n_mel:
+            raise ValueError('mel must be [batch, frames, {}], got {}'.format(self.n_mel, tuple(mel.shape)))
+        B, F = int(mel.shape[0]), int(mel.shape[1])
+        T = self.iaf_length(F)
+        noise = self._dev(noise)
+        if noise is not None and tuple(noise.shape) != (B, T):
+            raise ValueError('noise must be [{}, {}], got {}'.format(B, T, tuple(noise.shape)))
+        out = {}
+        new = lambda dt=torch.float32: torch.empty((B, T), dtype=dt, device=self.device)
+        wav = new()
+        idx = new(torch.int32) if 'idx' in want else None
+        xr = new() if 'x' in want else None
+        mt = new() if 'mean_tot' in want else None
+        st = new() if 'scale_tot' in want else None
+        ro = new() if 'rand_input' in want else None
+        with torch.cuda.device(self.device):
+            nb = self.lib.wn_workspace_bytes(self._h, B, F)
+            ws = self._workspace(nb)
+            self._check(self.lib.wn_iaf_generate(
+                self._h, _ptr(mel), B, F, _ptr(noise), ctypes.c_uint64(int(seed)), _ptr(wav), _ptr(idx),
+                _ptr(xr), _ptr(mt), _ptr(st), _ptr(ro), _ptr(ws), ws.numel(), self._stream()))
+        for k, v in (('wav', wav), ('idx', idx), ('x', xr), ('mean_tot', mt), ('scale_tot', st),
+                     ('rand_input', ro)):
+            if k in want:
+                out[k] = v
+        return out
+
+    def clip_quant(self, x):
+        x = self._dev(x)
+        wav = torch.empty_like(x)
+        idx = torch.empty(x.shape, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_clip_quant(self._h, _ptr(x), x.numel(), _ptr(wav), _ptr(idx), self._stream()))
+        return wav, idx
+
+    def deconv(self, mel, scope=None):
+        """Wavenet.deconv_stack: mel [B,F,n_mel] -> [B, F*frame_shift, deconv_width]."""
+        mel = self._dev(mel)
+        B, F = int(mel.shape[0]), int(mel.shape[1])
+        if scope is None:
+            scope = '' if self.kind == 'teacher' else \
+                ('iaf_share' if (getattr(self.hp, 'use_share_deconv', False) or
+                                 getattr(self.hp, 'use_teacher_deconv', False)) else 'iaf_1')
+        enc = torch.empty((B, F * self.frame_shift, self.hp.deconv_width), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.wn_workspace_bytes(self._h, B, F))
+            self._check(self.lib.wn_deconv(self._h, scope.encode(), _ptr(mel), B, F, _ptr(enc), _ptr(ws),
+                                           ws.numel(), self._stream()))
+        return enc
+
+    # ---- AR path ----
+    def ar_n_rand(self):
+        return int(self.lib.wn_ar_n_rand(self._h))
+
+    def ar_new_state(self, B):
+        n = self.lib.wn_ar_state_bytes(self._h, int(B))
+        if n == 0:
+            raise ValueError('not a finalized teacher engine')
+        st = torch.empty(int(n), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_ar_reset(self._h, _ptr(st), int(B), self._stream()))
+        return st
+
+    def ar_step(self, state, wav_in, enc_t, rnd=None, seed=0, want_out=False):
+        """One Fastgen.sample step.  wav_in [B] or [B,1]; enc_t [B,deconv_width]."""
+        wav_in = self._dev(wav_in).reshape(-1)
+        enc_t = self._dev(enc_t)
+        B = int(wav_in.shape[0])
+        rnd = self._dev(rnd)
+        sample = torch.empty((B,), dtype=torch.int32, device=self.device)
+        outp = torch.empty((B, cfg.teacher_out_width(self.hp)), dtype=torch.float32, device=self.device) \
+            if want_out else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_ar_step(self._h, _ptr(state), B, _ptr(wav_in), _ptr(enc_t), _ptr(rnd),
+                                            ctypes.c_uint64(int(seed)), _ptr(sample), _ptr(outp), self._stream()))
+        return (sample, outp) if want_out else sample
+
+    def ar_generate(self, enc, rnd=None, seed=0, forced_wav=None, want_out=False):
+        """fastgen.synthesis loop.  enc [B,Tn,deconv_width] -> dict(idx, wav[, out_params])."""
+        enc = self._dev(enc)
+        B, Tn = int(enc.shape[0]), int(enc.shape[1])
+        rnd = self._dev(rnd)
+        forced = self._dev(forced_wav)
+        idx = torch.empty((B, Tn), dtype=torch.int32, device=self.device)
+        wav = torch.empty((B, Tn), dtype=torch.float32, device=self.device)
+        outp = torch.empty((B, Tn, cfg.teacher_out_width(self.hp)), dtype=torch.float32, device=self.device) \
+            if want_out else None
+        with torch.cuda.device(self.device):
+            nb = self.lib.wn_ar_state_bytes(self._h, B)
+            ws = self._workspace(nb)
+            self._check(self.lib.wn_ar_generate(
+                self._h, _ptr(enc), B, Tn, _ptr(rnd), ctypes.c_uint64(int(seed)), _ptr(idx), _ptr(wav),
+                _ptr(forced), _ptr(outp), _ptr(ws), ws.numel(), self._stream()))
+        out = {'idx': idx, 'wav': wav}
+        if want_out:
+            out['out_params'] = outp
+        return out
