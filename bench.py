@@ -1,0 +1,189 @@
+"""Headline benchmark: 16 kHz audio samples/s of Parallel-WaveNet (IAF student)
+generation on MI355X -- BASELINE.json's metric on its configs[1]
+("parallel_wavenet.json IAF student gen, 1 MI355X, batch=1 synthetic 80-dim mel").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the whole generation hot path (noise draw, mel upsampler, 4 IAF
+flows = 60 fused residual-layer kernels + 4 heads, clip/quantise) over one batch of
+synthetic mels already resident in HBM.  Utterances are independent, so N ranks each
+generate their own batch with no data-path collective (weak scaling); the only
+communication is the one-time weight broadcast from rank 0 (untimed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nsynth_wavenet_amd import config as cfg            # noqa: E402
+from nsynth_wavenet_amd import dist as wdist             # noqa: E402
+from nsynth_wavenet_amd import weights as wts            # noqa: E402
+from nsynth_wavenet_amd.engine import Engine             # noqa: E402
+
+# per generated sample (BASELINE.md section 2 / SURVEY section 8d)
+LAYER_FLOP_PER_SAMPLE = 61440          # one residual layer: 2 * (12288 + 16384 + 2048) MAC
+LAYER_BYTES_PER_SAMPLE = 1536          # read l 256 B + read mel_en 1024 B + write l 256 B
+PATH_FLOP_PER_SAMPLE = 4385280
+PATH_BYTES_PER_SAMPLE = 98484
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def cpu_baseline(hp_dict, frames, budget_s=25.0):
+    """Reference-shaped CPU port (oracle/torch_ref.py, torch-CPU fp32, all host cores) on
+    the same config-2 utterance.  The reference's TF CPU path cannot run (no TensorFlow)."""
+    from oracle import wavenet_np as O
+    from oracle.torch_ref import StudentRef
+    hp = O.HP(hp_dict)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    ref = StudentRef(w, hp)
+    mel = np.random.RandomState(12345).uniform(0, 1, [1, frames, 80]).astype(np.float32)
+    T = O.iaf_length(frames, hp)
+    u = np.random.RandomState(12346).uniform(1e-5, 1 - 1e-5, [1, T])
+    noise = O.logistic_from_uniform(u, np.float32)
+    t0 = time.time()
+    ref.parallelgen(mel, noise)                     # warm-up
+    first = time.time() - t0
+    times = []
+    while len(times) < 5 and (sum(times) + first) < budget_s:
+        t0 = time.time()
+        ref.parallelgen(mel, noise)
+        times.append(time.time() - t0)
+    med = float(np.median(times)) if times else first
+    return {'value': T / med, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': 'torch-CPU fp32 restatement (oracle/torch_ref.py), 1 utterance F={} T={} batch 1, '
+                      'warm-up + median of {} runs; the reference TF path cannot run here'.format(
+                          frames, T, max(len(times), 1)),
+            'x_realtime': T / med / 16000.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-per-gpu', type=int, default=1)
+    ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
+    ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local = wdist.env_rank_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
+                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus {} ...'.format(args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        wdist.init_process_group('nccl')
+    dev = torch.device('cuda', local)
+
+    with open(args.config) as f:
+        hp_dict = json.load(f)
+    hp = cfg.load_hparams(hp_dict)
+    # random-init weights of the named architecture (no checkpoints offline); rank 0
+    # builds them, every other rank receives them in one RCCL broadcast over xGMI
+    weights = wts.synthetic_weights(hp, 'student', seed=1234, init='tf') if rank == 0 else None
+    weights = wdist.broadcast_weights(weights, hp, 'student', src=0, device=dev)
+    eng = Engine(hp, kind='student', device=dev).load_weights(weights)
+
+    B, F = args.batch_per_gpu, args.frames
+    T = eng.iaf_length(F)
+    mel = torch.from_numpy(np.random.RandomState(12345 + rank).uniform(0, 1, [B, F, 80]).astype(np.float32)).to(dev)
+
+    def step(i):
+        return eng.iaf_generate(mel, None, seed=1000 * rank + i, want=('wav',))['wav']
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wav = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    layer_ms, layer_launches = eng.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert wav.shape == (B, T) and bool(torch.isfinite(wav).all())
+
+    if rank == 0:
+        total_samples = world * B * T * args.steps
+        value = total_samples / elapsed
+        avg_layer_s = layer_ms * 1e-3 / max(layer_launches, 1)
+        flops_per_launch = LAYER_FLOP_PER_SAMPLE * B * T
+        achieved_tf = flops_per_launch / avg_layer_s / 1e12
+        rec = {
+            'metric': '16 kHz audio samples/sec, parallel-WaveNet (IAF student) generation',
+            'value': value,
+            'unit': 'samples/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE.json configs[1]: parallel_wavenet.json IAF student generation, '
+                            'synthetic 80-dim mel, 16 kHz, {} utterance(s) of {} frames = {} samples per GPU per step'
+                            .format(B, F, T),
+                'batch_per_gpu': B, 'frames': F, 'samples_per_utterance': T,
+                'x_realtime_per_gpu': value / world / 16000.0,
+                'samples_per_sec_per_gpu': value / world,
+                'weights': 'random-init (TF initialisers), seed 1234; noise drawn on device (Philox)',
+                'parallelism': 'utterance-sharded x{} (no data-path collective)'.format(world),
+                'path_gflop_per_step_per_gpu': PATH_FLOP_PER_SAMPLE * B * T / 1e9,
+                'path_achieved_tflops': PATH_FLOP_PER_SAMPLE * (total_samples / world) / elapsed / 1e12,
+                'path_algorithmic_GBps': PATH_BYTES_PER_SAMPLE * (total_samples / world) / elapsed / 1e9,
+            },
+            'roofline': {
+                'kernel': 'iaf_layer_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1)',
+                'bound': 'mfma',
+                'achieved': achieved_tf,
+                'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                'traffic': None,
+                'avg_launch_us': avg_layer_s * 1e6,
+                'launches': layer_launches,
+                'flop_per_launch': flops_per_launch,
+                'hbm_view': {'algorithmic_GBps': LAYER_BYTES_PER_SAMPLE * B * T / avg_layer_s / 1e9,
+                             'peak_GBps': PEAK_HBM_GBPS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec['cpu_baseline'] = cpu_baseline(hp_dict, F)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -198,6 +198,15 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
                    const float* forced_wav, float* out_params,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement aid used by bench.py (not part of the reference's surface, not
+ * thread-safe).  Between begin and end, wn_iaf_generate records a hipEvent pair
+ * on the caller's stream around every flow's run of residual-layer kernels
+ * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
+ * summed elapsed milliseconds and the number of layer-kernel launches they
+ * bracket, so that average launch duration = layer_ms / layer_launches. */
+int wn_profile_begin(wn_handle* h);
+int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches);
+
 /* Last error message of this handle (or of wn_create when h == NULL). */
 const char* wn_last_error(const wn_handle* h);
 

@@ -547,12 +547,22 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         }
         float* lin = lA;
         float* lout = lB;
+        if (h->prof_on) {
+            hipEvent_t e0, e1;
+            WN_HIP(h, hipEventCreate(&e0));
+            WN_HIP(h, hipEventCreate(&e1));
+            h->prof_events.push_back(e0);
+            h->prof_events.push_back(e1);
+            h->prof_launches += (int64_t)fp.layers.size();
+            WN_HIP(h, hipEventRecord(e0, st));
+        }
         for (const IafLayerPack& lp : fp.layers) {
             hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
                                lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
                                ntiles);
             float* t = lin; lin = lout; lout = t;
         }
+        if (h->prof_on) WN_HIP(h, hipEventRecord(h->prof_events.back(), st));
         hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
                            encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
                            tiles_per_row, ntiles);
@@ -581,3 +591,29 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 }
 
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F) { return iaf_layout(h, B, F).total; }
+
+extern "C" int wn_profile_begin(wn_handle* h) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_begin: null handle");
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    h->prof_events.clear();
+    h->prof_launches = 0;
+    h->prof_on = true;
+    return WN_OK;
+}
+
+extern "C" int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_end: null handle");
+    h->prof_on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_events.size(); i += 2) {
+        float f = 0.f;
+        WN_HIP(h, hipEventSynchronize(h->prof_events[i + 1]));
+        WN_HIP(h, hipEventElapsedTime(&f, h->prof_events[i], h->prof_events[i + 1]));
+        ms += f;
+    }
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    h->prof_events.clear();
+    if (layer_ms) *layer_ms = ms;
+    if (layer_launches) *layer_launches = h->prof_launches;
+    return WN_OK;
+}

@@ -80,6 +80,10 @@ struct wn_handle {
     mutable std::string err;
     // cached hipGraph for the AR step (wn_ar.hip)
     void* ar_graph_cache = nullptr;
+    // bench.py measurement aid (wn_profile_begin/end)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_events;     // begin/end pairs
+    int64_t prof_launches = 0;
 };
 
 // ---- error helpers ----

@@ -156,6 +156,16 @@ class Engine(object):
                                            ws.numel(), self._stream()))
         return enc
 
+    # ---- measurement aid (bench.py) ----
+    def profile_begin(self):
+        self._check(self.lib.wn_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> (summed ms of the bracketed residual-layer kernel runs, number of launches)."""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        self._check(self.lib.wn_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     # ---- AR path ----
     def ar_n_rand(self):
         return int(self.lib.wn_ar_n_rand(self._h))

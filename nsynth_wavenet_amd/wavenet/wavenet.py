@@ -1,0 +1,63 @@
+"""Host-side mirror of the reference's `Wavenet.deconv_stack` and `Fastgen`
+(wavenet/wavenet.py:94-155,318-514) for the generation path."""
+import numpy as np
+import torch
+
+from .. import config as cfg
+from ..engine import Engine
+
+
+class _TeacherBase(object):
+    def __init__(self, hparams, device=None, engine=None):
+        self.hparams = cfg.load_hparams(hparams)
+        hp = self.hparams
+        self.use_mu_law = hp.use_mu_law
+        self.loss_type = hp.loss_type
+        self.use_weight_norm = getattr(hp, 'use_weight_norm', False)
+        self.double_gate_width = getattr(hp, 'double_gate_width', True)
+        self.dropout_inputs = getattr(hp, 'dropout_inputs', False)
+        self.dropout_all = getattr(hp, 'dropout_all', False)
+        assert not (self.dropout_inputs and self.dropout_all)
+        self.quant_chann = cfg.quant_chann(hp)
+        self.out_width = cfg.teacher_out_width(hp)
+        self.engine = engine if engine is not None else Engine(hp, kind='teacher', device=device)
+
+    def load_weights(self, weights):
+        self.engine.load_weights(weights)
+        return self
+
+    def restore(self, checkpoint_path):
+        self.engine.load_checkpoint(checkpoint_path)
+        return self
+
+
+class Wavenet(_TeacherBase):
+    """Only the part of the teacher the generation path uses: the upsampler."""
+
+    def deconv_stack(self, mel_inputs, init=False):
+        return {'encoding': self.engine.deconv(mel_inputs['mel'])}
+
+
+class Fastgen(_TeacherBase):
+    """Incremental teacher: `sample({'wav': [B,1], 'encoding': [B,Cd]})` is one step.
+    The two FIFO queues per causal layer are a device-resident ring state created by
+    `init()` (the reference's sess.run(init_ops))."""
+
+    def __init__(self, hparams, batch_size=2, device=None, engine=None):
+        super(Fastgen, self).__init__(hparams, device, engine)
+        self.batch_size = batch_size
+        self.state = None
+
+    def init(self):
+        self.state = self.engine.ar_new_state(self.batch_size)
+        return self
+
+    def sample(self, inputs, rnd=None, seed=0, want_out=False):
+        if self.state is None:
+            self.init()
+        wav = inputs['wav']
+        res = self.engine.ar_step(self.state, wav, inputs['encoding'], rnd=rnd, seed=seed, want_out=want_out)
+        if want_out:
+            s, out = res
+            return {'sample': s.reshape(self.batch_size, 1), 'out_params': out}
+        return {'sample': res.reshape(self.batch_size, 1)}

@@ -1,0 +1,121 @@
+"""GPU parity tests of the autoregressive (fastgen) path through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('tag', ['ar_mol', 'ar_ce_mulaw', 'ar_gauss'])
+def test_golden_ar(tag):
+    """deconv (fastgen.encode), K1 (teacher-forced step outputs == full-sequence teacher),
+    free-running loop vs the oracle loop, sampler exactness on the engine's own logits,
+    and the single-step API with explicit queue state (tests/test_fastgen.py shape)."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, tag + '.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    B, Tn = g['forced'].shape
+    enc = _np(eng.deconv(g['mel']))
+    assert enc.shape == g['enc'].shape and np.abs(enc - g['enc']).max() <= 1e-5
+    assert eng.ar_length(g['mel'].shape[1]) == Tn
+    # K1
+    out = eng.ar_generate(g['enc'], g['rnd'], forced_wav=g['forced'], want_out=True)
+    assert np.abs(_np(out['out_params']) - g['out_forced']).max() <= 2e-5 * max(1.0, np.abs(g['out_forced']).max())
+    # free run
+    out = eng.ar_generate(g['enc'], g['rnd'], want_out=True)
+    gi = _np(out['idx'])
+    Q = 256 if cfgd['use_mu_law'] else 65536
+    assert gi.min() >= -Q // 2 and gi.max() < Q // 2
+    fg = O.Fastgen(w, hp, B, np.float32)
+    # the sampling head is exact given the engine's own network output ...
+    gop = _np(out['out_params'])
+    mism = sum(int((fg.sample_from(gop[:, t], g['rnd'][t]) != gi[:, t]).sum()) for t in range(Tn))
+    assert mism <= max(1, B * Tn // 50)        # <= 1 LSB flips where libm rounding crosses floor()
+    # ... the fed-back audio is the de-quantised index ...
+    assert np.abs(_np(out['wav']) - fg.dequant(gi)).max() <= 2.0 ** -23
+    # ... and the free-running index stream tracks the oracle loop until float noise forks it
+    diff = gi != g['free_idx']
+    first = int(np.argwhere(diff)[:, 1].min()) if diff.any() else Tn
+    assert first >= min(Tn, 8)
+    if not diff.any():
+        assert np.abs(_np(out['wav']) - g['free_wav']).max() <= 2.0 ** -23
+    # single-step API, reference test shape: wav [B,1], encoding [B,Cd]
+    st = eng.ar_new_state(B)
+    fg2 = O.Fastgen(w, hp, B, np.float32)
+    a = np.zeros([B], np.float32)
+    for t in range(12):
+        s, op = eng.ar_step(st, a, g['enc'][:, t], g['rnd'][t], want_out=True)
+        op_o = fg2.out_params(a.reshape(B, 1), g['enc'][:, t])
+        assert np.abs(_np(op) - op_o).max() <= 2e-5 * max(1.0, np.abs(op_o).max())
+        a = fg2.dequant(_np(s)).astype(np.float32)
+    eng.close()
+
+
+def test_full_width_teacher_short_run():
+    """wavenet_mol.json as shipped (width 512, 30 layers, MoL-10): K1 on a short prefix,
+    Philox sampling reproducible per seed, batch rows independent."""
+    import torch
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = load_json('wavenet_mol.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    B, Tn = 2, 512          # the full-sequence teacher needs T % 2^(num_stages-1) == 0 (masked.py:188)
+    rs = np.random.RandomState(0)
+    enc = (rs.standard_normal([B, Tn, 256]) * 0.3).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    out = eng.ar_generate(enc, None, seed=1, forced_wav=forced, want_out=True)
+    ref = O.teacher_feed_forward(forced.astype(np.float64), enc.astype(np.float64), w, hp, np.float64)
+    assert np.abs(_np(out['out_params']) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    a = eng.ar_generate(enc, None, seed=5)
+    b = eng.ar_generate(enc, None, seed=5)
+    c = eng.ar_generate(enc[:1], None, seed=5)
+    assert torch.equal(a['idx'], b['idx']) and torch.equal(a['idx'][:1], c['idx'])
+    assert eng.ar_n_rand() == 11
+    eng.close()
+
+
+def test_fastgen_mirror_and_cli(tmp_path):
+    """fastgen.encode_mel/synthesis and eval_wavenet.py write F*200 samples per utterance."""
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    from conftest import ROOT
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    from nsynth_wavenet_amd.wavenet.wavenet import Fastgen
+    cfgd = dict(load_json('wavenet_gauss.json'), width=128, skip_width=64, num_layers=4, num_stages=2)
+    hp = cfg.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=3)
+    ck = tmp_path / 'ckpt'
+    ck.mkdir()
+    wts.save_checkpoint(str(ck / 'model.ckpt-1'), w, hp)
+    (ck / 'wavenet_gauss.json').write_text(json.dumps(cfgd))
+    src = tmp_path / 'src'
+    src.mkdir()
+    np.save(str(src / 'u.npy'), np.random.RandomState(0).uniform(0, 1, [3, 80]).astype(np.float32))
+    out = tmp_path / 'out'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'eval_wavenet.py'), '--ckpt_dir', str(ck),
+                        '--source_path', str(src), '--save_path', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sr, a = wavfile.read(str(out / 'gen_u.wav'))
+    assert sr == 16000 and a.dtype == np.float32 and a.shape == (600,)
+    assert np.all(a.astype(np.float64) * 32768 == np.round(a.astype(np.float64) * 32768))
+    fg = Fastgen(hp, batch_size=4).load_weights(w).init()
+    np.random.seed(12345)                                   # tests/test_fastgen.py:28-32
+    s = fg.sample({'wav': np.random.uniform(-1, 1, [4, 1]), 'encoding': np.random.uniform(-1, 1, [4, 256])},
+                  rnd=np.zeros([4, 1], np.float32))
+    assert s['sample'].shape == (4, 1) and str(s['sample'].dtype) == 'torch.int32'

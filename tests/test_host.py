@@ -1,0 +1,220 @@
+"""CPU tests of the host-side logic and of the C-ABI library's surface (no compute calls)."""
+import ctypes
+import json
+import os
+import re
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_json
+from nsynth_wavenet_amd import _lib
+from nsynth_wavenet_amd import config as cfg
+from nsynth_wavenet_amd import weights as wts
+
+
+# the reference's own JSON (with its training-only keys) must load unchanged
+REFERENCE_STYLE_STUDENT = {
+    "lr_schedule": [[0, 1e-4], [90000, 6e-5]], "num_iters": 400000, "wave_length": 7680, "num_stages": 10,
+    "num_iaf_layers": [10, 10, 10, 30], "filter_length": 3, "width": 64, "deconv_width": 256,
+    "deconv_config": [[40, 10], [80, 20]], "use_mu_law": False, "loss_type": "logistic",
+    "use_weight_norm": False, "use_resize_conv": False, "use_share_deconv": True, "use_teacher_deconv": False,
+    "upsample_act": "leaky_relu", "num_samples": 100, "power_loss_factor": 1.0, "contrastive_loss_factor": 0.3}
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'wnhip.h')).read()
+    declared = sorted(set(re.findall(r'\b(wn_[a-z_0-9]+)\s*\(', header)))
+    assert 'wn_iaf_generate' in declared and 'wn_ar_generate' in declared and len(declared) >= 17
+    assert os.path.exists(_lib.LIB_PATH), 'run python -m nsynth_wavenet_amd.build'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert sorted(_lib.SYMBOLS) == declared
+    assert _lib.load().wn_abi_version() == 1
+
+
+def test_wn_config_struct_matches_header_layout():
+    # 7 scalars + 2*4 + 4 scalars + 8 + 7 scalars + 8 reserved = 42 int32
+    assert ctypes.sizeof(_lib.WnConfig) == 4 * (7 + 4 + 4 + 4 + 8 + 7 + 8)
+
+
+def test_create_without_gpu_fails_loudly_or_succeeds_on_gpu():
+    import torch
+    hp = cfg.load_hparams(REFERENCE_STYLE_STUDENT)
+    c = cfg.to_wn_config(hp)
+    h = ctypes.c_void_p(0)
+    rc = _lib.load().wn_create(ctypes.byref(c), ctypes.byref(h))
+    if torch.cuda.is_available():
+        assert rc == 0
+        _lib.load().wn_destroy(h)
+    else:
+        assert rc == -5 and b'no HIP device' in _lib.load().wn_last_error(None)
+        from nsynth_wavenet_amd.engine import Engine
+        with pytest.raises(RuntimeError):
+            Engine(hp)
+
+
+def test_invalid_configs_are_rejected_by_the_library():
+    lib = _lib.load()
+    for patch, frag in (({'filter_length': 5}, b'filter_length'), ({'width': 48}, b'specialised'),
+                        ({'deconv_config': [[40, 12], [80, 20]]}, b'deconv layer'),
+                        ({'num_stages': 12}, b'num_stages')):
+        d = dict(REFERENCE_STYLE_STUDENT)
+        d.update(patch)
+        c = cfg.to_wn_config(cfg.load_hparams(d))
+        h = ctypes.c_void_p(0)
+        assert lib.wn_create(ctypes.byref(c), ctypes.byref(h)) == -22
+        assert frag in lib.wn_last_error(None)
+    with pytest.raises(ValueError):
+        cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_resize_conv=True)))
+    with pytest.raises(ValueError):
+        cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_teacher_deconv=True)))
+
+
+def test_per_class_defaults():
+    ce = cfg.load_hparams(load_json('wavenet_ce.json'))
+    assert cfg.model_kind(ce) == 'teacher'
+    assert cfg.teacher_gate_width(ce) == 1024          # double_gate_width defaults to True
+    c = cfg.to_wn_config(ce)
+    assert (c.gate_width, c.out_width, c.use_mu_law, c.upsample_act) == (1024, 256, 1, _lib.ACT['tanh'])
+    mol = cfg.load_hparams(load_json('wavenet_mol.json'))
+    c = cfg.to_wn_config(mol)
+    assert (c.gate_width, c.out_width, c.mol_mix, c.loss_type) == (512, 30, 10, _lib.LOSS['mol'])
+    st = cfg.load_hparams(load_json('parallel_wavenet.json'))
+    c = cfg.to_wn_config(st)
+    assert (c.kind, c.share_deconv, c.n_flows, list(c.iaf_layers)[:4]) == (0, 1, 4, [10, 10, 10, 30])
+    g = cfg.load_hparams(load_json('parallel_wavenet_gauss.json'))
+    c = cfg.to_wn_config(g)
+    assert c.share_deconv == 0 and c.loss_type == _lib.LOSS['gauss']   # no use_share_deconv key -> private stacks
+    assert cfg.iaf_length(st, 773) == 154112 and cfg.iaf_length(st, 2) == 0 and cfg.frame_shift(st) == 200
+
+
+def test_expected_variables_and_synthetic_weights_match_oracle_generator():
+    from oracle import wavenet_np as O
+    for name, kind in (('parallel_wavenet.json', 'student'), ('parallel_wavenet_gauss.json', 'student'),
+                       ('wavenet_mol.json', 'teacher')):
+        d = load_json(name)
+        if kind == 'teacher':
+            d.update(width=64, skip_width=64, num_layers=3)
+        hp = cfg.load_hparams(d)
+        ev = wts.expected_variables(hp)
+        w = wts.synthetic_weights(hp, seed=7, init='tf')
+        wo = O.synth_weights(O.HP(d), kind, seed=7, init='tf')
+        assert sorted(w) == sorted(wo) == sorted(n for n, _ in ev)
+        for n, shape in ev:
+            assert w[n].shape == tuple(shape) == wo[n].shape
+    hp = cfg.load_hparams(load_json('parallel_wavenet.json'))
+    w = wts.synthetic_weights(hp)
+    assert w['iaf_1/out2_scale/biases'][0] == np.float32(-0.3) and w['iaf_1/out1/biases'].sum() == 0
+    assert abs(w['iaf_4/dilated_conv_30/W'].std() - 0.05) < 2e-3
+    wn = wts.expected_variables(cfg.load_hparams(dict(load_json('parallel_wavenet.json'), use_weight_norm=True)))
+    names = [n for n, _ in wn]
+    assert 'iaf_1/start_conv/W_V' in names and 'iaf_share/trans_conv_2/kernel_g' in names
+
+
+def test_checkpoint_round_trip_with_ema_keys(tmp_path):
+    d = load_json('parallel_wavenet.json')
+    d['num_iaf_layers'] = [1, 1]
+    hp = cfg.load_hparams(d)
+    w = wts.synthetic_weights(hp, seed=3)
+    p = wts.save_checkpoint(str(tmp_path / 'model.ckpt-12'), w, hp)
+    blob = np.load(p)
+    assert all(k.endswith(wts.EMA) for k in blob.files)                       # fastgen.py:12-14
+    back = wts.load_checkpoint(str(tmp_path / 'model.ckpt-12'), hp)
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    wts.save_checkpoint(str(tmp_path / 'model.ckpt-300'), w, hp)
+    assert wts.latest_checkpoint(str(tmp_path)).endswith('model.ckpt-300.npz')
+    (tmp_path / 'checkpoint').write_text('model_checkpoint_path: "model.ckpt-12"\n')
+    assert wts.latest_checkpoint(str(tmp_path)).endswith('model.ckpt-12')
+    # teacher-owned deconv variables are stored under raw names (parallelgen.py:31-39)
+    d2 = dict(d, use_share_deconv=False, use_teacher_deconv=True)
+    hp2 = cfg.load_hparams(d2)
+    p2 = wts.save_checkpoint(str(tmp_path / 'td'), w, hp2)
+    keys = np.load(p2).files
+    assert 'iaf_share/trans_conv_1/kernel' in keys and 'iaf_1/start_conv/W' + wts.EMA in keys
+    assert np.array_equal(wts.load_checkpoint(p2, hp2)['iaf_share/trans_conv_1/kernel'],
+                          w['iaf_share/trans_conv_1/kernel'])
+    bad = {k: v for k, v in w.items() if 'out2_mean' not in k}
+    p3 = wts.save_checkpoint(str(tmp_path / 'bad'), bad, hp)
+    with pytest.raises(KeyError):
+        wts.load_checkpoint(p3, hp)
+
+
+def test_cli_surface_and_source_discovery(tmp_path):
+    from nsynth_wavenet_amd import cli
+    a = cli.build_parser('x').parse_args(['--ckpt_dir', 'c', '--source_path', 's', '--save_path', 'o'])
+    assert (a.sample_length, a.batch_size, a.npy_only, a.log, a.gpu_id) == (-1, 1, False, 'INFO', '0')
+    for n in ('b.wav', 'a.wav', 'c.npy', 'notes.txt'):
+        (tmp_path / n).write_bytes(b'')
+    assert [os.path.basename(f) for f in cli.list_sources(str(tmp_path), False)] == ['a.wav', 'b.wav']
+    assert [os.path.basename(f) for f in cli.list_sources(str(tmp_path), True)] == ['c.npy']
+    assert cli.list_sources(str(tmp_path / 'a.wav'), False) == [str(tmp_path / 'a.wav')]
+    assert cli.list_sources(str(tmp_path / 'notes.txt'), False) == []
+    empty = tmp_path / 'e'
+    empty.mkdir()
+    (empty / 'x.txt').write_bytes(b'')
+    with pytest.raises(RuntimeError):
+        cli.list_sources(str(empty), False)
+    ck = tmp_path / 'ck'
+    ck.mkdir()
+    with pytest.raises(AssertionError):
+        cli.resolve_model(str(ck))
+    hp = cfg.load_hparams(dict(load_json('parallel_wavenet.json'), num_iaf_layers=[1]))
+    wts.save_checkpoint(str(ck / 'model.ckpt-5'), wts.synthetic_weights(hp), hp)
+    (ck / 'a.json').write_text(json.dumps(vars(hp)))
+    hp_back, path = cli.resolve_model(str(ck))
+    assert isinstance(hp_back, Namespace) and path.endswith('model.ckpt-5.npz')
+    (ck / 'b.json').write_text('{}')
+    with pytest.raises(AssertionError):
+        cli.resolve_model(str(ck))
+
+
+def test_load_batch_pads_and_save_batch_writes_float32_wav(tmp_path):
+    from scipy.io import wavfile
+    from nsynth_wavenet_amd.wavenet import fastgen
+    a = (np.sin(np.arange(3000) / 10.) * 20000).astype(np.int16)
+    b = (np.sin(np.arange(1800) / 7.) * 10000).astype(np.int16)
+    wavfile.write(str(tmp_path / 'a.wav'), 16000, a)
+    wavfile.write(str(tmp_path / 'b.wav'), 16000, b)
+    batch = fastgen.load_batch([str(tmp_path / 'a.wav'), str(tmp_path / 'b.wav')], sample_length=-1)
+    assert batch.shape == (2, 3000) and batch.dtype == np.float32
+    assert np.all(batch[1, 1800:] == 0) and abs(batch[0, 5] - a[5] / 32768.0) < 1e-7
+    assert fastgen.load_batch([str(tmp_path / 'a.wav')], sample_length=1000).shape == (1, 1000)
+    np.save(str(tmp_path / 'm1.npy'), np.ones([5, 80], np.float32))
+    np.save(str(tmp_path / 'm2.npy'), np.ones([3, 80], np.float32))
+    mb = fastgen.load_batch([str(tmp_path / 'm1.npy'), str(tmp_path / 'm2.npy')])
+    assert mb.shape == (2, 5, 80) and mb[1, 3:].sum() == 0
+    out = np.linspace(-1, 1, 64, dtype=np.float32)[None]
+    fastgen.save_batch(out, [str(tmp_path / 'gen_x.wav')])
+    sr, back = wavfile.read(str(tmp_path / 'gen_x.wav'))
+    assert sr == 16000 and back.dtype == np.float32 and np.array_equal(back, out[0])
+
+
+def test_mel_featuriser_shape_range_and_tone():
+    from nsynth_wavenet_amd.auxilaries import mel_extractor as M
+    y = (0.1 * np.random.RandomState(0).standard_normal(154480)).astype(np.float32)
+    m = M.melspectrogram(y)
+    assert m.shape == (773, 80) and m.dtype == np.float32           # K4: 1 + 154480 // 200 frames
+    assert m.min() >= 0 and m.max() <= 1
+    assert np.allclose(M.melspectrogram(np.zeros(4000, np.float32)), 40.0 / 140.0, atol=1e-6)   # floor: 1e-5 -> -100 dB
+    fb = M.mel_filterbank()
+    assert fb.shape == (80, 1025) and np.all(fb >= 0) and np.all(fb.sum(axis=1) > 0)
+    freqs = np.linspace(0, 8000, 1025)
+    assert fb[:, freqs < 125].sum() == 0 and fb[:, freqs > 7600].sum() == 0
+    t = np.arange(16000) / 16000.0
+    lo = M.melspectrogram((0.5 * np.sin(2 * np.pi * 500 * t)).astype(np.float32))[40].argmax()
+    hi = M.melspectrogram((0.5 * np.sin(2 * np.pi * 4000 * t)).astype(np.float32))[40].argmax()
+    assert lo < hi
+    assert M.batch_melspectrogram(np.stack([y[:4000], y[4000:8000]])).shape == (2, 21, 80)
+
+
+def test_host_codecs_match_oracle():
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.auxilaries import utils
+    q = np.arange(-128, 128)
+    assert np.array_equal(utils.inv_mu_law_numpy(q), O.inv_mu_law(q))
+    x = np.random.RandomState(0).uniform(-1, 1, 1000).astype(np.float32)
+    assert np.array_equal(utils.mu_law_numpy(x), O.mu_law(x))
+    assert np.array_equal(utils.cast_quantize_numpy(x, 65536), O.cast_quantize(x, 65536))
