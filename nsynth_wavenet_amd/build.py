@@ -43,7 +43,8 @@ def build(force=False, verbose=True):
     objs = []
     hipcc = find_hipcc()
     common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
-              '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+              '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + \
+        os.environ.get('WN_EXTRA_FLAGS', '').split()
     procs = []
     for s in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(s)[0] + '.o')

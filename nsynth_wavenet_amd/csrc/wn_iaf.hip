@@ -107,103 +107,156 @@ __global__ void iaf_start_kernel(const float* __restrict__ x, const float* __res
 }
 
 // ---------------- fused residual layer ----------------
+// Buffer-addressed loads: base pointer + size live in a scalar resource descriptor, the
+// per-lane part of the address is ONE VGPR per tap that stays constant for a tile, and the
+// row (channel) offset is a scalar soffset -- no per-load 64-bit VALU address arithmetic.
+__device__ inline float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// NOTE: pass the value as a plain float.  hipcc (ROCm 7.2) miscompiles
+// raw_buffer_store_b32(__builtin_bit_cast(unsigned, vec[r]), ...) on an MFMA accumulator
+// vector: every r stores element 0 (seen in the ISA as four stores of a0).
+__device__ inline void buf_st(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// One-shot staging of a packed weight image into LDS: ALL loads of a thread are issued
+// before the first LDS store (a load->store loop serialises ~30 L2 round trips per thread,
+// which cost more than the layer's MFMA time).
+template <int NFLOATS>
+__device__ inline void stage_weights(const float* __restrict__ wpack, float* lds) {
+    constexpr int NF4 = NFLOATS / 4, NCHUNK = NF4 / 256, REM = NF4 - NCHUNK * 256;
+    const f4* src = reinterpret_cast<const f4*>(wpack) + threadIdx.x;
+    f4* dst = reinterpret_cast<f4*>(lds) + threadIdx.x;
+    f4 tmp[NCHUNK + 1];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) tmp[k] = src[k * 256];
+    if (REM && (int)threadIdx.x < REM) tmp[NCHUNK] = src[NCHUNK * 256];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) dst[k * 256] = tmp[k];
+    if (REM && (int)threadIdx.x < REM) dst[NCHUNK * 256] = tmp[NCHUNK];
+    __syncthreads();
+}
+
+struct TileSrc {                      // where one wave finds the B operands of one tile
+    __amdgpu_buffer_rsrc_t rl, re;    // residual stream rows / upsampled-mel rows of the batch element
+    int vo[3];                        // per-lane byte offset for taps t-2d, t-d, t
+    int ve;                           // per-lane byte offset into enc
+};
+
 __global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
     const float* __restrict__ lin, float* __restrict__ lout, const float* __restrict__ enc,
     const float* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    {
-        const f4* src = reinterpret_cast<const f4*>(wpack);
-        f4* dst = reinterpret_cast<f4*>(lds);
-        for (int i = threadIdx.x; i < IAF_LAYER_FLOATS / 4; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
+    stage_weights<IAF_LAYER_FLOATS>(wpack, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
     const f4* PRl = Pl + IAF_P_FLOATS / 4;
     const float* bg = lds + IAF_P_FLOATS + IAF_PR_FLOATS + q * 16;
     const float* br = bg + 64;
+    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
+    const int lane_l = (4 * q * (int)RS + wave * 16 + n + IAF_LP) * 4;
+    const int lane_e = (4 * q * (int)TE + wave * 16 + n) * 4;
 
+    auto tile_src = [&](int tile) -> TileSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * 64;
+        TileSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = lane_l + (tt - 2 * d) * 4;
+        s.vo[1] = lane_l + (tt - d) * 4;
+        s.vo[2] = lane_l + tt * 4;
+        s.ve = lane_e + tt * 4;
+        return s;
+    };
+    // 28 K-groups of 4 K-steps (16 MFMAs each): groups 0-11 = the three causal taps t-2d,
+    // t-d, t of the dilated conv (4 groups of 16 channels each), groups 12-27 = the
+    // conditioning 1x1 over the 256 upsampled-mel channels.
+    auto loadB = [&](const TileSrc& s, int g) -> f4 {
+        f4 v;
+        if (g < 12) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.rl, s.vo[g >> 2], (16 * (g & 3) + jj) * RS4);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.re, s.ve, (16 * (g - 12) + jj) * TE4);
+        }
+        return v;
+    };
+    // The f32 MFMA is slow (32 cycles per instruction per SIMD) and this kernel runs one wave
+    // per SIMD, so memory latency is hidden by distance, not occupancy: as soon as K-group g of
+    // tile i has been multiplied, the B operands of group g of the wave's NEXT tile are loaded
+    // into the same registers -- every load is issued one whole tile (~15k cycles) before its
+    // use, with a single 112-register operand set and no copies.  Weights (A) are read from
+    // LDS one K-group ahead into the other half of a register double buffer.
+    f4 bcur[28];
+    if ((int)blockIdx.x < ntiles) {
+        const TileSrc s0 = tile_src(blockIdx.x);
+#pragma unroll
+        for (int g = 0; g < 28; ++g) bcur[g] = loadB(s0, g);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_row;
-        const int t0 = (tile - b * tiles_per_row) * 64 + wave * 16;
-        const float* lrow = lin + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
-        const float* erow = enc + (size_t)b * IAF_CD * TE + t0 + n;
+        const int tt = (tile - b * tiles_per_row) * 64;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const TileSrc sn = tile_src(has_next ? next : tile);
 
-        f4 acc[4], cur[4];
+        f4 acc[4], cur[4], a[2][4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bg + mb * 4);
-
-        // 28 K-groups of 4 K-steps (16 MFMAs each): groups 0-11 = the three causal taps
-        // t-2d, t-d, t of the dilated conv (4 groups of 16 channels each), groups 12-27 =
-        // the conditioning 1x1 over the 256 upsampled-mel channels.  Software pipeline:
-        // weights (A) are read from LDS one group ahead, activations (B) from global two
-        // groups ahead, so the f32 MFMA pipe (32 cycles/instruction) never waits on memory.
-        auto loadA = [&](int g, f4 (&a)[4]) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = Pl[(g * 4 + mb) * 64];
-        };
-        auto loadB = [&](int g) -> f4 {
-            const float* p;
-            int64_t stride;
-            if (g < 12) {
-                p = lrow + (int64_t)(16 * (g & 3) + 4 * q) * RS - (2 - (g >> 2)) * d;
-                stride = RS;
-            } else {
-                p = erow + (int64_t)(16 * (g - 12) + 4 * q) * TE;
-                stride = TE;
+        for (int mb = 0; mb < 4; ++mb) a[0][mb] = Pl[mb * 64];
+#pragma unroll
+        for (int g = 0; g < 28; ++g) {
+            if (g + 1 < 28) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) a[(g + 1) & 1][mb] = Pl[((g + 1) * 4 + mb) * 64];
             }
-            return (f4){p[0], p[stride], p[2 * stride], p[3 * stride]};
-        };
-        f4 a1[4], b1, b2;
-        loadA(0, a1);
-        b1 = loadB(0);
-        b2 = loadB(1);
-        auto group = [&](int g) -> f4 {
-            f4 a0[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a0[mb] = a1[mb];
-            const f4 b0 = b1;
-            b1 = b2;
-            if (g + 1 < 28) loadA(g + 1, a1);
-            if (g + 2 < 28) b2 = loadB(g + 2);
+            if (g >= 8 && g < 12) cur[g - 8] = bcur[g];      // tap t is also the residual C-in
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a0[mb][jj], b0[jj], acc[mb]);
-            return b0;
-        };
-#pragma unroll 1
-        for (int g = 0; g < 8; ++g) group(g);
-#pragma unroll
-        for (int g = 8; g < 12; ++g) cur[g - 8] = group(g);     // tap t: also the residual C-in
-#pragma unroll 1
-        for (int g = 12; g < 28; ++g) group(g);
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a[g & 1][mb][jj], bcur[g][jj], acc[mb]);
+            // pin the order inside the group: next group's 4 LDS weight reads FIRST (so their
+            // latency hides under this group's 16 MFMAs), then the MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if (has_next) bcur[g] = loadB(sn, g);
+            // keep the schedule group-by-group: without this fence the scheduler hoists every
+            // LDS weight read of the unrolled loop to the top and spills hundreds of registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
-        f4 g[2];
+        f4 gt[2];
 #pragma unroll
         for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[mg][r] = sigmoidf_(acc[mg][r]) * tanhf_(acc[mg + 2][r]);
-        // residual 1x1, accumulated onto l
+            for (int r = 0; r < 4; ++r) gt[mg][r] = sigmoidf_(acc[mg][r]) * tanhf_(acc[mg + 2][r]);
+        // residual 1x1 accumulated onto l: the tap-t operands (groups 8-11) are the C-in
         f4 d2[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) d2[mb] = cur[mb] + *reinterpret_cast<const f4*>(br + mb * 4);
 #pragma unroll
         for (int j4 = 0; j4 < 2; ++j4) {
-            f4 a[4];
+            f4 ar[4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = PRl[(j4 * 4 + mb) * 64];
+            for (int mb = 0; mb < 4; ++mb) ar[mb] = PRl[(j4 * 4 + mb) * 64];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) d2[mb] = mfma4(a[mb][jj], g[j4][jj], d2[mb]);
+                for (int mb = 0; mb < 4; ++mb) d2[mb] = mfma4(ar[mb][jj], gt[j4][jj], d2[mb]);
         }
-        float* orow = lout + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
+        const __amdgpu_buffer_rsrc_t ro =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        const int vo_out = lane_l + tt * 4;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) orow[(size_t)(16 * mb + 4 * q + r) * RS] = d2[mb][r];
+            for (int r = 0; r < 4; ++r)
+                buf_st(d2[mb][r], ro, vo_out, (16 * mb + r) * RS4);
     }
 }
 
@@ -221,12 +274,7 @@ __global__ __launch_bounds__(256, 1) void iaf_head_kernel(
     float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
     int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    {
-        const f4* src = reinterpret_cast<const f4*>(wpack);
-        f4* dst = reinterpret_cast<f4*>(lds);
-        for (int i = threadIdx.x; i < IAF_HEAD_FLOATS / 4; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
+    stage_weights<IAF_HEAD_FLOATS>(wpack, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
@@ -234,45 +282,69 @@ __global__ __launch_bounds__(256, 1) void iaf_head_kernel(
     const float* wm = bo + 64;
     const float* wsc = wm + 64;
     const float bmean = lds[IAF_PH_FLOATS + 192], bscale = lds[IAF_PH_FLOATS + 193];
+    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
+    const int lane_l = (4 * q * (int)RS + wave * 16 + n + IAF_LP) * 4;
+    const int lane_e = (4 * q * (int)TE + wave * 16 + n) * 4;
 
+    // 20 K-groups: 0-3 = out1 over relu(l), 4-19 = mel_cond_out1 over the 256 enc channels;
+    // same one-tile-ahead operand prefetch as iaf_layer_kernel.
+    auto tile_src = [&](int tile) -> TileSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * 64;
+        TileSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 4;
+        s.ve = lane_e + tt * 4;
+        return s;
+    };
+    auto loadB = [&](const TileSrc& s, int g) -> f4 {
+        f4 v;
+        if (g < 4) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.rl, s.vo[2], (16 * g + jj) * RS4);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.re, s.ve, (16 * (g - 4) + jj) * TE4);
+        }
+        return v;
+    };
+    f4 bcur[20];
+    if ((int)blockIdx.x < ntiles) {
+        const TileSrc s0 = tile_src(blockIdx.x);
+#pragma unroll
+        for (int g = 0; g < 20; ++g) bcur[g] = loadB(s0, g);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_row;
         const int t0 = (tile - b * tiles_per_row) * 64 + wave * 16;
-        const float* lrow = lin + (size_t)b * IAF_W * RS + IAF_LP + t0 + n;
-        const float* erow = enc + (size_t)b * IAF_CD * TE + t0 + n;
-        f4 acc[4];
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const TileSrc sn = tile_src(has_next ? next : tile);
+        f4 acc[4], a[2][4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bo + mb * 4);
-        // 20 K-groups: 0-3 = out1 over relu(l), 4-19 = mel_cond_out1 over the 256 enc channels
-        auto loadA = [&](int g, f4 (&a)[4]) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = Pl[(g * 4 + mb) * 64];
-        };
-        auto loadB = [&](int g) -> f4 {
-            if (g < 4) {
-                const float* p = lrow + (int64_t)(16 * g + 4 * q) * RS;
-                return (f4){fmaxf(p[0], 0.f), fmaxf(p[RS], 0.f), fmaxf(p[2 * RS], 0.f), fmaxf(p[3 * RS], 0.f)};
-            }
-            const float* p = erow + (int64_t)(16 * (g - 4) + 4 * q) * TE;
-            return (f4){p[0], p[TE], p[2 * TE], p[3 * TE]};
-        };
-        f4 a1[4], b1, b2;
-        loadA(0, a1);
-        b1 = loadB(0);
-        b2 = loadB(1);
-#pragma unroll 1
+        for (int mb = 0; mb < 4; ++mb) a[0][mb] = Pl[mb * 64];
+#pragma unroll
         for (int g = 0; g < 20; ++g) {
-            f4 a0[4];
+            if (g + 1 < 20) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a0[mb] = a1[mb];
-            const f4 b0 = b1;
-            b1 = b2;
-            if (g + 1 < 20) loadA(g + 1, a1);
-            if (g + 2 < 20) b2 = loadB(g + 2);
+                for (int mb = 0; mb < 4; ++mb) a[(g + 1) & 1][mb] = Pl[((g + 1) * 4 + mb) * 64];
+            }
+            f4 bv = bcur[g];
+            if (g < 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bv[jj] = fmaxf(bv[jj], 0.f);        // relu(l), :256
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a0[mb][jj], b0[jj], acc[mb]);
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(a[g & 1][mb][jj], bv[jj], acc[mb]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if (has_next) bcur[g] = loadB(sn, g);
+            __builtin_amdgcn_sched_barrier(0);
         }
         float pm = 0.f, ps = 0.f;
 #pragma unroll

@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC passes for the dominant kernel (run on the GPU box through gpurun). $1 = tag
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o sq -- $CMD > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d $OUT/inst -o inst -- $CMD > $OUT/inst.log 2>&1
+ls -R $OUT | head -30
+python - <<PY
+import csv, glob, collections, os
+out = "$OUT"
+for sub in ("sq", "fetch", "write", "inst"):
+    files = glob.glob(os.path.join(out, sub, "*counter_collection.csv"))
+    if not files:
+        print(sub, "no counter file"); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for row in csv.DictReader(open(files[0])):
+        k = row["Kernel_Name"].split("(")[0][-40:]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
+        cnt[(k, row["Counter_Name"])] += 1
+    for k in agg:
+        if "iaf_layer" in k or "deconv_mfma" in k or "iaf_head" in k:
+            print(sub, k, {c: round(v / cnt[(k, c)], 1) for c, v in agg[k].items()}, "dispatches", max(cnt[(k, c)] for c in agg[k]))
+PY
