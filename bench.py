@@ -39,6 +39,23 @@ PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4
 PEAK_HBM_GBPS = 8000.0
 
 
+def pmc_traffic(B, F):
+    """HBM bytes per iaf_layer_kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
+    PMC counters cannot be collected from inside this process, so this is the value of the
+    profiled run of the SAME command; None when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        w = d['workload']
+        if (w['batch_per_gpu'], w['frames']) != (B, F):
+            return None
+        return d['kernels']['iaf_layer_kernel']['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(hp_dict, frames, budget_s=25.0):
     """Reference-shaped CPU port (oracle/torch_ref.py, torch-CPU fp32, all host cores) on
     the same config-2 utterance.  The reference's TF CPU path cannot run (no TensorFlow)."""
@@ -184,7 +201,9 @@ def main():
                 'peak': PEAK_F32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                'traffic': None,
+                'traffic': pmc_traffic(B, F),
+                'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)',
+                'algorithmic_bytes_per_launch': LAYER_BYTES_PER_SAMPLE * B * T,
                 'avg_launch_us': avg_layer_s * 1e6,
                 'launches': layer_launches,
                 'flop_per_launch': flops_per_launch,

@@ -12,6 +12,8 @@
 // Activations are kept CHANNEL-MAJOR ([C][time]) everywhere on the device so that
 // the B operand of v_mfma_f32_16x16x4_f32 (lane = (k>>?, n)) is a coalesced
 // time-contiguous load and dilation / tap shifts are plain column offsets.
+#include <algorithm>
+
 #include "wn_internal.h"
 
 
@@ -46,11 +48,13 @@ __device__ inline float apply_act(float v, int act) {
 
 // One workgroup = 4 waves; wave w owns output channels [64*(4*zc + w), +64) as 4
 // MFMA row blocks; all waves share the same 64 q columns (their B loads hit L1).
+// The GEMM result of phase r is written PHASE-MAJOR, yp[b][r][co][q] (16 contiguous bytes
+// per lane, full lines per row); deconv_interleave_kernel then weaves the S phases into
+// time order.  Writing y[co][S*q + r - pL] directly from here would be a 4-byte scatter at
+// stride S*4 bytes -- measured 8.8x HBM write amplification (rocprofv3 WRITE_SIZE).
 __global__ __launch_bounds__(256) void deconv_mfma_kernel(
-    const float* __restrict__ x, int cin, int xs,
-    const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ y, int cout, int64_t ys, int yoff,
-    int L, int S, int pL, int taps, int act, int zc_count) {
+    const float* __restrict__ x, int cin, int xs, const float* __restrict__ wp,
+    float* __restrict__ yp, int cout, int Qp, int S, int taps, int zc_count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const int r = blockIdx.y;
@@ -71,42 +75,65 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(
     const f4* wpr = reinterpret_cast<const f4*>(wp) + ((size_t)r * nks4 * nmb + cg * 4) * 64 + lane;
     const float* xb = x + (size_t)b * cin * xs + DC_XOFF + q0 + DC_NT * n;
 
-    for (int j = 0; j < taps; ++j) {
-        for (int c4 = 0; c4 < cblk; ++c4) {
-            const int ks4 = j * cblk + c4;
-            f4 a[4];
+    // operands of K-group `it` (tap j = it / cblk, channel block c4 = it % cblk), loaded one
+    // group ahead of the 64 MFMAs that consume them
+    auto load = [&](int it, f4 (&a)[4], f4 (&bv)[4]) {
+        const int j = it / cblk, c4 = it - j * cblk;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = wpr[((size_t)ks4 * nmb + mb) * 64];
-            f4 bv[4];
+        for (int mb = 0; mb < 4; ++mb) a[mb] = wpr[((size_t)it * nmb + mb) * 64];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int ci = 16 * c4 + 4 * jj + kq;
-                bv[jj] = *reinterpret_cast<const f4u*>(xb + (size_t)ci * xs - j);
-            }
+        for (int jj = 0; jj < 4; ++jj)
+            bv[jj] = *reinterpret_cast<const f4u*>(xb + (size_t)(16 * c4 + 4 * jj + kq) * xs - j);
+    };
+    f4 a1[4], b1[4];
+    load(0, a1, b1);
+    for (int it = 0; it < nks4; ++it) {
+        f4 a[4], bv[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+        for (int i = 0; i < 4; ++i) { a[i] = a1[i]; bv[i] = b1[i]; }
+        if (it + 1 < nks4) load(it + 1, a1, b1);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int e = 0; e < DC_NT; ++e)
-                        acc[mb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][jj], bv[jj][e], acc[mb][e], 0, 0, 0);
-        }
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int e = 0; e < DC_NT; ++e)
+                    acc[mb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][jj], bv[jj][e], acc[mb][e], 0, 0, 0);
     }
-
-    const int64_t SL = (int64_t)S * L;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int co = 64 * cg + 16 * mb + 4 * kq + rr;
-            const float bco = bias[co];
-            float* yr = y + ((size_t)b * cout + co) * ys + yoff;
-#pragma unroll
-            for (int e = 0; e < DC_NT; ++e) {
-                const int64_t nn = (int64_t)S * (q0 + DC_NT * n + e) + r - pL;
-                if (nn >= 0 && nn < SL) yr[nn] = apply_act(acc[mb][e][rr] + bco, act);
-            }
+            float* row = yp + (((size_t)b * S + r) * cout + co) * Qp + q0 + DC_NT * n;
+            *reinterpret_cast<f4*>(row) = (f4){acc[mb][0][rr], acc[mb][1][rr], acc[mb][2][rr], acc[mb][3][rr]};
         }
+}
+
+// yp[b][r][co][q] -> y[b][co][yoff + S*q + r - pL] with bias + activation.  One workgroup =
+// one channel x 64 q columns = S*64 consecutive output samples, transposed through LDS so
+// that both the reads (64 contiguous q per phase row) and the writes are full lines.
+constexpr int DI_MAXS = 32;
+__global__ __launch_bounds__(256) void deconv_interleave_kernel(
+    const float* __restrict__ yp, const float* __restrict__ bias, float* __restrict__ y,
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act) {
+    __shared__ float tile[DI_MAXS][DC_QT + 1];
+    const int co = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * DC_QT;
+    for (int i = threadIdx.x; i < S * DC_QT; i += 256) {
+        const int r = i / DC_QT, q = i - r * DC_QT;
+        tile[r][q] = yp[(((size_t)b * S + r) * cout + co) * Qp + q0 + q];
+    }
+    __syncthreads();
+    const float bco = bias[co];
+    const int64_t SL = (int64_t)S * L;
+    float* yr = y + ((size_t)b * cout + co) * ys + yoff;
+    const int64_t n0 = (int64_t)S * q0 - pL;
+    for (int i = threadIdx.x; i < S * DC_QT; i += 256) {
+        const int q = i / S, r = i - q * S;
+        const int64_t nn = n0 + i;
+        if (nn >= 0 && nn < SL) yr[nn] = apply_act(tile[r][q] + bco, act);
+    }
 }
 
 // channel-major [B][C][T] (row stride cs) -> reference layout [B][T][C]
@@ -177,7 +204,20 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
-// scratch: channel-major mel + every intermediate layer output
+// phase-major GEMM output of the largest layer: [B][S][cout][Qp]
+static size_t dc_phase_floats(const wn_handle* h, int B, int F) {
+    const wn_config& c = h->cfg;
+    size_t mx = 0;
+    int64_t L = F;
+    for (int j = 0; j < c.n_deconv; ++j) {
+        const size_t Qp = (size_t)((L + 2 + DC_QT - 1) / DC_QT) * DC_QT;
+        mx = std::max(mx, (size_t)B * c.deconv_stride[j] * c.deconv_width * Qp);
+        L *= c.deconv_stride[j];
+    }
+    return mx;
+}
+
+// scratch: channel-major mel + every intermediate layer output + the phase-major buffer
 size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F) {
     const wn_config& c = h->cfg;
     size_t fl = (size_t)B * c.n_mel * dc_row_stride(F);
@@ -186,6 +226,7 @@ size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F) {
         L *= c.deconv_stride[j];
         fl += (size_t)B * c.deconv_width * dc_row_stride((int)L);
     }
+    fl += dc_phase_floats(h, B, F);
     return align_up(fl * sizeof(float), 256);
 }
 
@@ -201,6 +242,9 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
     }
     const float* x = buf;
     float* next = buf + (size_t)B * c.n_mel * xs;
+    // the phase-major buffer sits at the end of the scratch area
+    float* phase = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + wn_deconv_scratch_bytes(h, B, F)) -
+                   dc_phase_floats(h, B, F);
     int L = F;
     for (int j = 0; j < c.n_deconv; ++j) {
         const DeconvLayerPack& lp = sp.layers[j];
@@ -216,11 +260,14 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
         }
         const int Q = L + 2;
+        const int Qp = ((Q + DC_QT - 1) / DC_QT) * DC_QT;
         const int zc = (lp.cout + 255) / 256;
-        dim3 g((Q + DC_QT - 1) / DC_QT, lp.S, B * zc);
-        hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off,
-                           h->d_blob + lp.b_off, y, lp.cout, ys, yoff, L, lp.S, lp.pL, lp.taps,
-                           c.upsample_act, zc);
+        dim3 g(Qp / DC_QT, lp.S, B * zc);
+        hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off, phase,
+                           lp.cout, Qp, lp.S, lp.taps, zc);
+        dim3 gi(Qp / DC_QT, lp.cout, B);
+        hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,
+                           lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
         x = y;
         xs = (int)ys;
         next = y + (size_t)B * lp.cout * ys;

@@ -70,6 +70,9 @@ static int validate(const wn_config& c) {
             return wn_fail(nullptr, WN_EINVAL,
                            "config: deconv layer %d (filter %d, stride %d) unsupported: need "
                            "filter %% stride == 0 and (filter-stride) even", j, K, S);
+        if (S > 32 || K / S > 8)
+            return wn_fail(nullptr, WN_EINVAL, "config: deconv layer %d: stride <= 32 and filter/stride <= 8 "
+                           "are the supported range, got filter %d stride %d", j, K, S);
     }
     if (c.n_mel < 4 || c.n_mel % 4 || c.deconv_width % 64 || c.deconv_width < 64)
         return wn_fail(nullptr, WN_EINVAL, "config: n_mel %% 4 and deconv_width %% 64 must be 0");
