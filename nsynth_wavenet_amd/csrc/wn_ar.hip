@@ -81,6 +81,12 @@ __global__ void ar_start_kernel(float* __restrict__ state, ArStateLayout L, ArDi
     if (c == 0) ur[(t & 3) * D.B + b] = u;
 }
 
+// Per-lane slice of a GEMV row: K is walked in chunks of AR_KC f4 per lane, and inside a
+// chunk EVERY load (weights, then the batch's inputs) is issued before the first use -- a
+// plain `for k` loop waits one L2/Infinity-Cache round trip per iteration, which at batch 1
+// was most of the step time.  Weights are held in registers across the batch loop.
+constexpr int AR_KC = 4;                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
+
 // ---- generic row GEMV: y[b][o] (op)= bias[o] + W[o][:] . x[b][:]  (masked.py:383-405) ----
 // MODE 0: skip_start  s  = .            x = l
 // MODE 1: res/skip    l += . (o<W) and ring push of the old l; s += . (o>=W)   x = g
@@ -98,30 +104,41 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
     const long long ti = per_step ? 0 : t;
     const float* wrow = Wm + (size_t)o * K;
     const float bo = bias[o];
+    auto xptr = [&](int b, int k) -> const float* {
+        if (MODE == 0) return state + L.l + (size_t)b * D.W + k;
+        if (MODE == 1) return state + L.g + (size_t)b * (D.G / 2) + k;
+        if (MODE == 2) return k < D.S ? state + L.s + (size_t)b * D.S + k
+                                      : enc + ((size_t)b * Tn + ti) * D.Cd + (k - D.S);
+        return state + L.z + (size_t)b * D.S + k;
+    };
     for (int b0 = 0; b0 < D.B; b0 += AR_BT) {
         float acc[AR_BT];
 #pragma unroll
         for (int e = 0; e < AR_BT; ++e) acc[e] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const f4 w = *reinterpret_cast<const f4*>(wrow + k);
+        for (int kc = 0; kc < K; kc += AR_KC * 256) {
+            f4 w[AR_KC];
+#pragma unroll
+            for (int i = 0; i < AR_KC; ++i) {
+                const int k = kc + i * 256 + lane * 4;
+                w[i] = k < K ? *reinterpret_cast<const f4*>(wrow + k) : (f4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int e = 0; e < AR_BT; ++e) {
                 const int b = b0 + e;
-                if (b < D.B) {
-                    f4 xv;
-                    if (MODE == 0) xv = *reinterpret_cast<const f4*>(state + L.l + (size_t)b * D.W + k);
-                    else if (MODE == 1) xv = *reinterpret_cast<const f4*>(state + L.g + (size_t)b * (D.G / 2) + k);
-                    else if (MODE == 2) {
-                        if (k < D.S) {
-                            xv = *reinterpret_cast<const f4*>(state + L.s + (size_t)b * D.S + k);
+                if (b >= D.B) break;
+                f4 xv[AR_KC];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) xv[i] = fmaxf(xv[i], 0.f);          // wavenet.py:494
-                        } else {
-                            xv = *reinterpret_cast<const f4*>(enc + ((size_t)b * Tn + ti) * D.Cd + (k - D.S));
-                        }
-                    } else xv = *reinterpret_cast<const f4*>(state + L.z + (size_t)b * D.S + k);
-                    acc[e] += w[0] * xv[0] + w[1] * xv[1] + w[2] * xv[2] + w[3] * xv[3];
+                for (int i = 0; i < AR_KC; ++i) {
+                    const int k = kc + i * 256 + lane * 4;
+                    xv[i] = k < K ? *reinterpret_cast<const f4*>(xptr(b, k)) : (f4){0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 2 && k < D.S) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) xv[i][c] = fmaxf(xv[i][c], 0.f);       // wavenet.py:494
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < AR_KC; ++i)
+                    acc[e] += w[i][0] * xv[i][0] + w[i][1] * xv[i][1] + w[i][2] * xv[i][2] + w[i][3] * xv[i][3];
             }
         }
 #pragma unroll
@@ -166,25 +183,38 @@ __global__ __launch_bounds__(256) void ar_gate_kernel(
     const float* ring = state + L.rings + (size_t)D.B * ring_off;
     const size_t slot2 = (size_t)(t % (2 * dil)) * D.B;            // x[t-2d]
     const size_t slot1 = (size_t)((t + dil) % (2 * dil)) * D.B;    // x[t-d]
+    auto xptr = [&](int b, int k) -> const float* {
+        if (k < D.W) return ring + (slot2 + b) * D.W + k;
+        if (k < 2 * D.W) return ring + (slot1 + b) * D.W + (k - D.W);
+        if (k < 3 * D.W) return state + L.l + (size_t)b * D.W + (k - 2 * D.W);
+        return enc + ((size_t)b * Tn + ti) * D.Cd + (k - 3 * D.W);
+    };
     for (int b0 = 0; b0 < D.B; b0 += AR_BT) {
         float a0[AR_BT], a1[AR_BT];
 #pragma unroll
         for (int e = 0; e < AR_BT; ++e) a0[e] = a1[e] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const f4 wa = *reinterpret_cast<const f4*>(w0 + k);
-            const f4 wb = *reinterpret_cast<const f4*>(w1 + k);
+        for (int kc = 0; kc < K; kc += AR_KC * 256) {
+            f4 wa[AR_KC], wb[AR_KC];
+#pragma unroll
+            for (int i = 0; i < AR_KC; ++i) {
+                const int k = kc + i * 256 + lane * 4;
+                wa[i] = k < K ? *reinterpret_cast<const f4*>(w0 + k) : (f4){0.f, 0.f, 0.f, 0.f};
+                wb[i] = k < K ? *reinterpret_cast<const f4*>(w1 + k) : (f4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int e = 0; e < AR_BT; ++e) {
                 const int b = b0 + e;
-                if (b < D.B) {
-                    const float* src;
-                    if (k < D.W) src = ring + (slot2 + b) * D.W + k;
-                    else if (k < 2 * D.W) src = ring + (slot1 + b) * D.W + (k - D.W);
-                    else if (k < 3 * D.W) src = state + L.l + (size_t)b * D.W + (k - 2 * D.W);
-                    else src = enc + ((size_t)b * Tn + ti) * D.Cd + (k - 3 * D.W);
-                    const f4 xv = *reinterpret_cast<const f4*>(src);
-                    a0[e] += wa[0] * xv[0] + wa[1] * xv[1] + wa[2] * xv[2] + wa[3] * xv[3];
-                    a1[e] += wb[0] * xv[0] + wb[1] * xv[1] + wb[2] * xv[2] + wb[3] * xv[3];
+                if (b >= D.B) break;
+                f4 xv[AR_KC];
+#pragma unroll
+                for (int i = 0; i < AR_KC; ++i) {
+                    const int k = kc + i * 256 + lane * 4;
+                    xv[i] = k < K ? *reinterpret_cast<const f4*>(xptr(b, k)) : (f4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int i = 0; i < AR_KC; ++i) {
+                    a0[e] += wa[i][0] * xv[i][0] + wa[i][1] * xv[i][1] + wa[i][2] * xv[i][2] + wa[i][3] * xv[i][3];
+                    a1[e] += wb[i][0] * xv[i][0] + wb[i][1] * xv[i][1] + wb[i][2] * xv[i][2] + wb[i][3] * xv[i][3];
                 }
             }
         }
