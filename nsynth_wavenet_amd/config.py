@@ -56,9 +56,23 @@ def iaf_length(hparams, num_frames):
     return (num_frames * frame_shift(hparams) // md) * md
 
 
-def to_wn_config(hparams, kind=None, n_mel=80):
+PRECISIONS = {'f16x3': 0, 'f32': 1}
+
+
+def default_precision():
+    """IAF contraction arithmetic: 'f16x3' = split-fp16 operands on the fp16 MFMA (three MFMAs per
+    product, ~22-bit operands, fp32 accumulate) -- the default; 'f32' = fp32 MFMA."""
+    import os
+    return os.environ.get('WN_PRECISION', 'f16x3')
+
+
+def to_wn_config(hparams, kind=None, n_mel=80, precision=None):
     kind = kind or model_kind(hparams)
     c = _lib.WnConfig()
+    precision = precision or default_precision()
+    if precision not in PRECISIONS:
+        raise ValueError('precision must be one of {}'.format(sorted(PRECISIONS)))
+    c.reserved[0] = PRECISIONS[precision]
     if getattr(hparams, 'use_resize_conv', False):
         raise ValueError('use_resize_conv=true is not supported (disabled in every shipped config)')
     dc = hparams.deconv_config

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "wn_internal.h"
+#include "wn_codec.h"
 
 
 namespace {
@@ -157,6 +158,37 @@ __global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// Same, but the output is written as split-fp16 pair planes (wn_codec.h): one workgroup =
+// one channel PAIR x 64 q columns; hi words to row cp, lo words to row cout/2 + cp.
+__global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
+    const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act) {
+    __shared__ float tile[2][DI_MAXS][DC_QT + 1];
+    const int cp = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * DC_QT;
+    for (int i = threadIdx.x; i < 2 * S * DC_QT; i += 256) {
+        const int h = i / (S * DC_QT), j = i - h * S * DC_QT;
+        const int r = j / DC_QT, q = j - r * DC_QT;
+        tile[h][r][q] = yp[(((size_t)b * S + r) * cout + 2 * cp + h) * Qp + q0 + q];
+    }
+    __syncthreads();
+    const float b0 = bias[2 * cp], b1 = bias[2 * cp + 1];
+    const int64_t SL = (int64_t)S * L;
+    unsigned* yh = y + ((size_t)b * cout + cp) * ys + yoff;
+    unsigned* yl = yh + (size_t)(cout / 2) * ys;
+    const int64_t n0 = (int64_t)S * q0 - pL;
+    for (int i = threadIdx.x; i < S * DC_QT; i += 256) {
+        const int q = i / S, r = i - q * S;
+        const int64_t nn = n0 + i;
+        if (nn >= 0 && nn < SL) {
+            unsigned hw, lw;
+            wn_split_pair(apply_act(tile[0][r][q] + b0, act), apply_act(tile[1][r][q] + b1, act), hw, lw);
+            yh[nn] = hw;
+            yl[nn] = lw;
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -231,7 +263,7 @@ size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F) {
 }
 
 int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* enc_cm,
-                  int64_t enc_stride, void* scratch, hipStream_t st) {
+                  int64_t enc_stride, void* scratch, hipStream_t st, bool split_out) {
     const wn_config& c = h->cfg;
     const DeconvStackPack& sp = h->stacks[si];
     float* buf = reinterpret_cast<float*>(scratch);
@@ -265,9 +297,16 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         dim3 g(Qp / DC_QT, lp.S, B * zc);
         hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off, phase,
                            lp.cout, Qp, lp.S, lp.taps, zc);
-        dim3 gi(Qp / DC_QT, lp.cout, B);
-        hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,
-                           lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
+        if (last && split_out) {
+            dim3 gi(Qp / DC_QT, lp.cout / 2, B);
+            hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
+                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL,
+                               c.upsample_act);
+        } else {
+            dim3 gi(Qp / DC_QT, lp.cout, B);
+            hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,
+                               lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
+        }
         x = y;
         xs = (int)ys;
         next = y + (size_t)B * lp.cout * ys;

@@ -80,6 +80,8 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: num_stages must be in 1..10");
     if (c.upsample_act < 0 || c.upsample_act > 2)
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
+    if (c.reserved[0] != WN_PREC_F16X3 && c.reserved[0] != WN_PREC_F32)
+        return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.reserved[0]);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.width != IAF_W || c.gate_width != IAF_W || c.deconv_width != IAF_CD)
             return wn_fail(nullptr, WN_EINVAL,
@@ -210,6 +212,10 @@ extern "C" int wn_finalize(wn_handle* h) {
     if (rc) return rc;
     rc = h->cfg.kind == WN_KIND_STUDENT ? wn_pack_iaf(h, blob) : wn_pack_ar(h, blob);
     if (rc) return rc;
+    if (h->cfg.kind == WN_KIND_STUDENT) {
+        rc = wn_pack_iaf_h(h, blob);
+        if (rc) return rc;
+    }
     WN_HIP(h, hipSetDevice(h->device));
     h->blob_floats = blob.size();
     WN_HIP(h, hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float)));

@@ -568,8 +568,11 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     void* scratch = base + L.scratch;
     const wn_config& c = h->cfg;
 
+    const bool f16x3 = c.reserved[0] == WN_PREC_F16X3;
     static bool attr_done = false;
     if (!attr_done) {
+        int rc = wn_iaf_h_set_attrs(h);
+        if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_LAYER_FLOATS * sizeof(float)));
@@ -599,7 +602,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         }
     }
     if (c.share_deconv) {
-        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st);
+        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3);
         if (rc) return rc;
     }
     const int tiles_per_row = (int)(L.T / 64);
@@ -609,10 +612,12 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     for (int k = 0; k < c.n_flows; ++k) {
         const IafFlowPack& fp = h->flows[k];
         if (!c.share_deconv) {
-            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st);
+            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3);
             if (rc) return rc;
         }
-        {
+        if (f16x3) {
+            wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st);
+        } else {
             dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
             hipLaunchKernelGGL(iaf_start_kernel, g, dim3(256), 0, st, x, h->d_blob + fp.start_off, lA, L.T,
                                L.XR, L.RS);
@@ -629,15 +634,22 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
             WN_HIP(h, hipEventRecord(e0, st));
         }
         for (const IafLayerPack& lp : fp.layers) {
-            hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
-                               lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
-                               ntiles);
+            if (f16x3)
+                wn_iaf_h_layer(lin, lout, encc, h->d_blob + lp.off_h, L.RS, L.TE, lp.dilation, B, L.T, h->num_cu, st);
+            else
+                hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
+                                   lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
+                                   ntiles);
             float* t = lin; lin = lout; lout = t;
         }
         if (h->prof_on) WN_HIP(h, hipEventRecord(h->prof_events.back(), st));
-        hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
-                           encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
-                           tiles_per_row, ntiles);
+        if (f16x3)
+            wn_iaf_h_head(lin, encc, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0, B,
+                          h->num_cu, st);
+        else
+            hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
+                               encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
+                               tiles_per_row, ntiles);
     }
     {
         const int64_t nn = (int64_t)B * L.T;

@@ -1,0 +1,587 @@
+// Split-fp16 ("f16x3") variant of the IAF kernels: same math and same structure as
+// wn_iaf.hip, but every contraction runs on v_mfma_f32_16x16x32_f16 as
+//   a*b ~= ah*bh + ah*bl + al*bh      (hi = f16(x), lo = f16(x - hi), fp32 accumulate)
+// which costs 3 fp16 MFMAs (3 x 16 cycles for K = 32) instead of 8 fp32 MFMAs (8 x 32
+// cycles): 5.3x less matrix-pipe time at ~22-bit operand precision.  The kernels then stop
+// being MFMA-bound and become bound by streaming `enc` (1 KB/sample/layer) -- the HBM
+// roofline of BASELINE.md.
+//
+// Activations are stored as pair planes (wn_codec.h): l [B][2][32][LP+T] words,
+// enc [B][2][128][TE] words -- the same bytes as the fp32 layout of wn_iaf.hip.
+// K order inside a 32-channel MFMA K-step s: k-slot (kg = lane>>4, e) <-> channel
+//   32*s + 16*(e>>2) + 4*kg + (e&3)
+// so that the four operand words of a lane are pair rows 16*s + {0,1,8,9} + 2*kg, and so that
+// the operand registers of the tap-t K-steps are exactly the accumulator-layout C-in of the
+// residual 1x1 and the gated registers are its B operand (see wn_iaf.hip).
+#include <algorithm>
+#include <cmath>
+
+#include "wn_internal.h"
+#include "wn_codec.h"
+
+namespace {
+
+constexpr float EXP_M9 = 1.2340980408667956e-4f;
+constexpr float EXP_7 = 1096.6331584284585f;
+constexpr int HN = 2;                         // 16-column MFMA tiles per wave (dwordx2 loads)
+constexpr int H_TILE = 64 * HN;               // samples per workgroup tile (4 waves)
+
+__device__ inline f4 mfma_h(wn_u4 a, wn_u4 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, a), __builtin_bit_cast(wn_h8, b), c, 0, 0, 0);
+}
+__device__ inline f4 mfma3(wn_u4 ah, wn_u4 al, wn_u4 bh, wn_u4 bl, f4 c) {
+    c = mfma_h(ah, bh, c);
+    c = mfma_h(ah, bl, c);
+    return mfma_h(al, bh, c);
+}
+__device__ inline float sigmoidf_(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
+__device__ inline float tanhf_(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * a) + 1.f); }
+
+__device__ inline wn_u2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(wn_u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ inline void buf_st2(unsigned w0, unsigned w1, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wn_u2, (wn_u2){w0, w1}), r, voff, soff, 0);
+}
+
+template <int NWORDS>
+__device__ inline void stage_words(const unsigned* __restrict__ wpack, unsigned* lds) {
+    constexpr int NV = NWORDS / 4, NCHUNK = NV / 256, REM = NV - NCHUNK * 256;
+    const wn_u4* src = reinterpret_cast<const wn_u4*>(wpack) + threadIdx.x;
+    wn_u4* dst = reinterpret_cast<wn_u4*>(lds) + threadIdx.x;
+    wn_u4 tmp[NCHUNK + 1];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) tmp[k] = src[k * 256];
+    if (REM && (int)threadIdx.x < REM) tmp[NCHUNK] = src[NCHUNK * 256];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) dst[k * 256] = tmp[k];
+    if (REM && (int)threadIdx.x < REM) dst[NCHUNK * 256] = tmp[NCHUNK];
+    __syncthreads();
+}
+
+struct HSrc {
+    __amdgpu_buffer_rsrc_t rl, re;
+    int vo[3];
+    int ve;
+};
+
+// operand words of one K-step: rows {0,1,8,9}, hi and lo plane, HN columns each
+struct KOp {
+    wn_u2 h[4], l[4];
+};
+
+// ---------------- start conv -> split l  (parallel_wavenet.py:222-225) ----------------
+__global__ void iaf_start_h_kernel(const float* __restrict__ x, const float* __restrict__ wb,
+                                   unsigned* __restrict__ l, int64_t T, int XR, int64_t RS) {
+    const int b = blockIdx.y;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t >= T) return;
+    const float* xp = x + (size_t)b * XR + IAF_XP + t;
+    float xv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xv[i] = xp[i - 3];
+    unsigned* hp = l + (size_t)b * IAF_W * RS + IAF_LP + t;
+    unsigned* lp = hp + (size_t)(IAF_W / 2) * RS;
+    for (int cp = 0; cp < IAF_W / 2; ++cp) {
+        float o[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * cp + h;
+            const float w0 = wb[c], w1 = wb[IAF_W + c], w2 = wb[2 * IAF_W + c], bb = wb[3 * IAF_W + c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[h][e] = bb + w0 * xv[e] + w1 * xv[e + 1] + w2 * xv[e + 2];
+        }
+        wn_u4 hw, lw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned a, c2;
+            wn_split_pair(o[0][e], o[1][e], a, c2);
+            hw[e] = a;
+            lw[e] = c2;
+        }
+        *reinterpret_cast<wn_u4*>(hp + (size_t)cp * RS) = hw;
+        *reinterpret_cast<wn_u4*>(lp + (size_t)cp * RS) = lw;
+    }
+}
+
+// ---------------- fused residual layer ----------------
+__global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
+    const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const unsigned* __restrict__ enc,
+    const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    stage_words<IAF_LAYER_H_WORDS>(wpack, ldsw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
+    const wn_u4* PRl = Pl + 14 * 4 * 2 * 64;
+    const float* ldsf = reinterpret_cast<const float*>(ldsw);
+    const float* bg = ldsf + IAF_P_FLOATS + IAF_PR_FLOATS + q * 16;
+    const float* br = bg + 64;
+    const float inv_m = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 128], inv_r = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 129];
+    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
+    const int lane_l = (2 * q * (int)RS + wave * 16 * HN + HN * n + IAF_LP) * 4;
+    const int lane_e = (2 * q * (int)TE + wave * 16 * HN + HN * n) * 4;
+
+    auto tile_src = [&](int tile) -> HSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        HSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = lane_l + (tt - 2 * d) * 4;
+        s.vo[1] = lane_l + (tt - d) * 4;
+        s.vo[2] = lane_l + tt * 4;
+        s.ve = lane_e + tt * 4;
+        return s;
+    };
+    // K-steps 0-5: taps t-2d, t-d, t (two 32-channel steps each); 6-13: the 256 enc channels
+    auto loadK = [&](const HSrc& s, int ks) -> KOp {
+        KOp o;
+        constexpr int rows[4] = {0, 1, 8, 9};
+        if (ks < 6) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o.h[i] = buf_ld2(s.rl, s.vo[ks >> 1], (16 * (ks & 1) + rows[i]) * RS4);
+                o.l[i] = buf_ld2(s.rl, s.vo[ks >> 1], (32 + 16 * (ks & 1) + rows[i]) * RS4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o.h[i] = buf_ld2(s.re, s.ve, (16 * (ks - 6) + rows[i]) * TE4);
+                o.l[i] = buf_ld2(s.re, s.ve, (128 + 16 * (ks - 6) + rows[i]) * TE4);
+            }
+        }
+        return o;
+    };
+
+    KOp bc[14];
+    if ((int)blockIdx.x < ntiles) {
+        const HSrc s0 = tile_src(blockIdx.x);
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) bc[ks] = loadK(s0, ks);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const HSrc sn = tile_src(has_next ? next : tile);
+
+        f4 acc[4][HN];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < HN; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+        KOp cur[2];
+        wn_u4 a[2][4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            a[0][mb][0] = Pl[((0 * 4 + mb) * 2 + 0) * 64];
+            a[0][mb][1] = Pl[((0 * 4 + mb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            if (ks + 1 < 14) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = Pl[(((ks + 1) * 4 + mb) * 2 + 0) * 64];
+                    a[(ks + 1) & 1][mb][1] = Pl[(((ks + 1) * 4 + mb) * 2 + 1) * 64];
+                }
+            }
+            if (ks == 4 || ks == 5) cur[ks - 4] = bc[ks];          // tap t: also the residual C-in
+#pragma unroll
+            for (int e = 0; e < HN; ++e) {
+                const wn_u4 bh = {bc[ks].h[0][e], bc[ks].h[1][e], bc[ks].h[2][e], bc[ks].h[3][e]};
+                const wn_u4 bl = {bc[ks].l[0][e], bc[ks].l[1][e], bc[ks].l[2][e], bc[ks].l[3][e]};
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bh, bl, acc[mb][e]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12 * HN, 0);
+            if (has_next) bc[ks] = loadK(sn, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue per column tile: gate, residual 1x1, split, store
+        const __amdgpu_buffer_rsrc_t ro =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        const int vo_out = lane_l + tt * 4;
+        wn_u4 ar[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            ar[mb][0] = PRl[(mb * 2 + 0) * 64];
+            ar[mb][1] = PRl[(mb * 2 + 1) * 64];
+        }
+        unsigned oh[4][2][HN], ol[4][2][HN];
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
+            float g[2][4];
+#pragma unroll
+            for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
+                               tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
+            wn_u4 gh, gl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned hw, lw;
+                wn_split_pair(g[i >> 1][(i & 1) * 2], g[i >> 1][(i & 1) * 2 + 1], hw, lw);
+                gh[i] = hw;
+                gl[i] = lw;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f4 rc = mfma3(ar[mb][0], ar[mb][1], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
+                // l_old for channels 16mb+4q+r sits in K-step 4+(mb>>1), words (mb&1)*2 + (r>>1)
+                float lo_[4];
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp)
+                    wn_join_pair(cur[mb >> 1].h[(mb & 1) * 2 + rp][e], cur[mb >> 1].l[(mb & 1) * 2 + rp][e],
+                                 lo_[2 * rp], lo_[2 * rp + 1]);
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const float v0 = lo_[2 * rp] + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
+                    const float v1 = lo_[2 * rp + 1] + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
+                    wn_split_pair(v0, v1, oh[mb][rp][e], ol[mb][rp][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                buf_st2(oh[mb][rp][0], oh[mb][rp][1], ro, vo_out, (8 * mb + rp) * RS4);
+                buf_st2(ol[mb][rp][0], ol[mb][rp][1], ro, vo_out, (32 + 8 * mb + rp) * RS4);
+            }
+    }
+}
+
+// ---------------- flow head (parallel_wavenet.py:256-277, :319-324) ----------------
+__device__ inline float softplus_tf(float p) {
+    const float thr = -13.942384719848633f;      // tf.nn.softplus: log(eps) + 2
+    if (p > -thr) return p;
+    if (p < thr) return expf(p);
+    return log1pf(expf(p));
+}
+
+__global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
+    const unsigned* __restrict__ lin, const unsigned* __restrict__ enc, const unsigned* __restrict__ wpack,
+    float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
+    int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    stage_words<IAF_HEAD_FLOATS>(wpack, ldsw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;
+    const float* ldsf = reinterpret_cast<const float*>(ldsw);
+    const float* bo = ldsf + IAF_PH_FLOATS + q * 16;
+    const float* wm = bo + 64;
+    const float* wsc = wm + 64;
+    const float bmean = ldsf[IAF_PH_FLOATS + 192], bscale = ldsf[IAF_PH_FLOATS + 193];
+    const float inv_m = ldsf[IAF_PH_FLOATS + 194];
+    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
+    const int lane_l = (2 * q * (int)RS + wave * 16 * HN + HN * n + IAF_LP) * 4;
+    const int lane_e = (2 * q * (int)TE + wave * 16 * HN + HN * n) * 4;
+
+    auto tile_src = [&](int tile) -> HSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        HSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 4;
+        s.ve = lane_e + tt * 4;
+        return s;
+    };
+    // K-steps 0-1: out1 over relu(l); 2-9: mel_cond_out1 over the 256 enc channels
+    auto loadK = [&](const HSrc& s, int ks) -> KOp {
+        KOp o;
+        constexpr int rows[4] = {0, 1, 8, 9};
+        if (ks < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o.h[i] = buf_ld2(s.rl, s.vo[2], (16 * ks + rows[i]) * RS4);
+                o.l[i] = buf_ld2(s.rl, s.vo[2], (32 + 16 * ks + rows[i]) * RS4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o.h[i] = buf_ld2(s.re, s.ve, (16 * (ks - 2) + rows[i]) * TE4);
+                o.l[i] = buf_ld2(s.re, s.ve, (128 + 16 * (ks - 2) + rows[i]) * TE4);
+            }
+        }
+        return o;
+    };
+    KOp bc[10];
+    if ((int)blockIdx.x < ntiles) {
+        const HSrc s0 = tile_src(blockIdx.x);
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) bc[ks] = loadK(s0, ks);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row;
+        const int t0 = (tile - b * tiles_per_row) * H_TILE + wave * 16 * HN;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const HSrc sn = tile_src(has_next ? next : tile);
+        f4 acc[4][HN];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < HN; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+        wn_u4 a[2][4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            a[0][mb][0] = Pl[((0 * 4 + mb) * 2 + 0) * 64];
+            a[0][mb][1] = Pl[((0 * 4 + mb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) {
+            if (ks + 1 < 10) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = Pl[(((ks + 1) * 4 + mb) * 2 + 0) * 64];
+                    a[(ks + 1) & 1][mb][1] = Pl[(((ks + 1) * 4 + mb) * 2 + 1) * 64];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < HN; ++e) {
+                wn_u4 bh = {bc[ks].h[0][e], bc[ks].h[1][e], bc[ks].h[2][e], bc[ks].h[3][e]};
+                wn_u4 bl = {bc[ks].l[0][e], bc[ks].l[1][e], bc[ks].l[2][e], bc[ks].l[3][e]};
+                if (ks < 2) {                         // relu(l) (:256) on the reconstructed value
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v0, v1;
+                        wn_join_pair(bh[i], bl[i], v0, v1);
+                        unsigned hw, lw;
+                        wn_split_pair(fmaxf(v0, 0.f), fmaxf(v1, 0.f), hw, lw);
+                        bh[i] = hw;
+                        bl[i] = lw;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bh, bl, acc[mb][e]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            if (has_next) bc[ks] = loadK(sn, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            float pm = 0.f, ps = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = fmaxf(fmaf(acc[mb][e][r], inv_m, bo[mb * 4 + r]), 0.f);
+                    pm = fmaf(wm[mb * 4 + r], o, pm);
+                    ps = fmaf(wsc[mb * 4 + r], o, ps);
+                }
+            pm += __shfl_xor(pm, 16);
+            ps += __shfl_xor(ps, 16);
+            pm += __shfl_xor(pm, 32);
+            ps += __shfl_xor(ps, 32);
+            if (q == 0) {
+                const int64_t t = t0 + HN * n + e;
+                const float mean = pm + bmean;
+                const float s = fminf(fmaxf(softplus_tf(ps + bscale), EXP_M9), EXP_7);   // :105-114
+                float* xp = x + (size_t)b * XR + IAF_XP + t;
+                *xp = *xp * s + mean;                                                    // :277
+                float* mp = Mt + (size_t)b * T + t;
+                float* sp = St + (size_t)b * T + t;
+                if (first) { *mp = mean; *sp = s; }
+                else { *mp = mean + *mp * s; *sp = *sp * s; }                            // :322-323
+            }
+        }
+    }
+}
+
+// ---- host-side fp32 -> fp16 (round to nearest even), independent of host _Float16 support ----
+uint16_t f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));   // inf / nan
+    if (x < 0x38800000u) {                         // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(x >> 23);     // 14..24
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t rnd = 1u << (shift - 1);
+        const uint32_t rem = m & ((1u << shift) - 1);
+        m >>= shift;
+        if (rem > rnd || (rem == rnd && (m & 1))) ++m;
+        return (uint16_t)(sign | m);
+    }
+    uint32_t m = x - 0x38000000u;                   // rebias exponent
+    const uint32_t rem = m & 0x1fffu;
+    m >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (m & 1))) ++m;
+    return (uint16_t)(sign | m);
+}
+float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// power-of-two prescale so that the lo halves of small weights stay normal fp16 numbers
+float pick_scale(const float* w, size_t nw) {
+    float mx = 0.f;
+    for (size_t i = 0; i < nw; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.f)) return 1.f;
+    int k = (int)std::floor(std::log2(16384.0f / mx));
+    k = std::max(-8, std::min(k, 14));
+    return std::ldexp(1.0f, k);
+}
+
+// write the A-fragment words of one (K-step, row block): plane 0 = hi, plane 1 = lo
+// wk(e, kg, i16) returns the (prescaled) weight of k-slot (kg, e) for output row i16
+template <class F>
+void pack_afrag(unsigned* dst, F wk) {
+    for (int plane = 0; plane < 2; ++plane)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 4; ++i) {
+                const int i16 = lane & 15, kg = lane >> 4;
+                uint16_t hh[2];
+                for (int p = 0; p < 2; ++p) {
+                    const float v = wk(2 * i + p, kg, i16);
+                    const uint16_t hi = f2h(v);
+                    hh[p] = plane == 0 ? hi : f2h(v - h2f(hi));
+                }
+                dst[(plane * 64 + lane) * 4 + i] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
+    const wn_config& c = h->cfg;
+    auto var = [&](const std::string& nme) -> const std::vector<float>& { return h->vars.at(nme).data; };
+    for (int k = 0; k < c.n_flows; ++k) {
+        const std::string p = "iaf_" + std::to_string(k + 1);
+        IafFlowPack& fp = h->flows[k];
+        for (int i = 0; i < c.iaf_layers[k]; ++i) {
+            const std::string s = std::to_string(i + 1);
+            std::vector<float> Wd = wn_get_kernel(h, p + "/dilated_conv_" + s, "W", false);   // [3][64][64]
+            std::vector<float> Wc = wn_get_kernel(h, p + "/mel_cond_" + s, "W", false);       // [256][64]
+            std::vector<float> Wr = wn_get_kernel(h, p + "/res_" + s, "W", false);            // [32][64]
+            const auto& bd = var(p + "/dilated_conv_" + s + "/biases");
+            const auto& bc = var(p + "/mel_cond_" + s + "/biases");
+            const auto& br = var(p + "/res_" + s + "/biases");
+            blob.resize(align_up(blob.size(), 64));
+            fp.layers[i].off_h = blob.size();
+            blob.resize(blob.size() + IAF_LAYER_H_WORDS);
+            unsigned* P = reinterpret_cast<unsigned*>(blob.data() + fp.layers[i].off_h);
+            float* tb = blob.data() + fp.layers[i].off_h + IAF_P_FLOATS + IAF_PR_FLOATS;
+            const float sm = std::min(pick_scale(Wd.data(), Wd.size()), pick_scale(Wc.data(), Wc.size()));
+            const float sr = pick_scale(Wr.data(), Wr.size());
+            for (int ks = 0; ks < 14; ++ks)
+                for (int mb = 0; mb < 4; ++mb)
+                    pack_afrag(P + ((size_t)(ks * 4 + mb) * 2) * 256, [&](int e, int kg, int i16) {
+                        const int o = 16 * mb + i16;
+                        const int ch = 16 * (e >> 2) + 4 * kg + (e & 3);
+                        if (ks < 6) return sm * Wd[((size_t)(ks >> 1) * 64 + 32 * (ks & 1) + ch) * 64 + o];
+                        return sm * Wc[((size_t)32 * (ks - 6) + ch) * 64 + o];
+                    });
+            for (int mb = 0; mb < 4; ++mb)
+                pack_afrag(P + IAF_P_FLOATS + (size_t)(mb * 2) * 256, [&](int e, int kg, int i16) {
+                    const int ch = 16 * (e >> 2) + 4 * kg + (e & 3);
+                    return sr * Wr[(size_t)ch * 64 + 16 * mb + i16];
+                });
+            for (int q = 0; q < 4; ++q)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * mb + 4 * q + r;
+                        tb[q * 16 + mb * 4 + r] = bd[o] + bc[o];
+                        tb[64 + q * 16 + mb * 4 + r] = br[o];
+                    }
+            tb[128] = 1.0f / sm;
+            tb[129] = 1.0f / sr;
+            tb[130] = tb[131] = 0.f;
+        }
+        {
+            std::vector<float> Wo = wn_get_kernel(h, p + "/out1", "W", false);            // [64][64]
+            std::vector<float> Wco = wn_get_kernel(h, p + "/mel_cond_out1", "W", false);  // [256][64]
+            std::vector<float> Wm = wn_get_kernel(h, p + "/out2_mean", "W", false);
+            std::vector<float> Ws = wn_get_kernel(h, p + "/out2_scale", "W", false);
+            const auto& bo = var(p + "/out1/biases");
+            const auto& bco = var(p + "/mel_cond_out1/biases");
+            blob.resize(align_up(blob.size(), 64));
+            fp.head_off_h = blob.size();
+            blob.resize(blob.size() + IAF_HEAD_FLOATS);
+            unsigned* P = reinterpret_cast<unsigned*>(blob.data() + fp.head_off_h);
+            float* tb = blob.data() + fp.head_off_h + IAF_PH_FLOATS;
+            const float sm = std::min(pick_scale(Wo.data(), Wo.size()), pick_scale(Wco.data(), Wco.size()));
+            for (int ks = 0; ks < 10; ++ks)
+                for (int mb = 0; mb < 4; ++mb)
+                    pack_afrag(P + ((size_t)(ks * 4 + mb) * 2) * 256, [&](int e, int kg, int i16) {
+                        const int o = 16 * mb + i16;
+                        const int ch = 16 * (e >> 2) + 4 * kg + (e & 3);
+                        if (ks < 2) return sm * Wo[((size_t)32 * ks + ch) * 64 + o];
+                        return sm * Wco[((size_t)32 * (ks - 2) + ch) * 64 + o];
+                    });
+            for (int q = 0; q < 4; ++q)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * mb + 4 * q + r;
+                        tb[q * 16 + mb * 4 + r] = bo[o] + bco[o];
+                        tb[64 + q * 16 + mb * 4 + r] = Wm[o];
+                        tb[128 + q * 16 + mb * 4 + r] = Ws[o];
+                    }
+            tb[192] = var(p + "/out2_mean/biases")[0];
+            tb[193] = var(p + "/out2_scale/biases")[0];
+            tb[194] = 1.0f / sm;
+            tb[195] = 0.f;
+        }
+    }
+    return WN_OK;
+}
+
+int wn_iaf_h_set_attrs(wn_handle* h) {
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_H_WORDS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_h_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * 4));
+    return WN_OK;
+}
+
+void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st) {
+    dim3 g((unsigned)((T / 4 + 255) / 256), B);
+    hipLaunchKernelGGL(iaf_start_h_kernel, g, dim3(256), 0, st, x, wb, reinterpret_cast<unsigned*>(l), T, XR, RS);
+}
+
+void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
+                    int d, int B, int64_t T, int num_cu, hipStream_t st) {
+    const int tiles_per_row = (int)(T / H_TILE), ntiles = B * tiles_per_row;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(iaf_layer_h_kernel, dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st,
+                       reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout),
+                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wpack), RS, TE, d,
+                       tiles_per_row, ntiles);
+}
+
+void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
+                   int64_t RS, int64_t TE, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st) {
+    const int tiles_per_row = (int)(T / H_TILE), ntiles = B * tiles_per_row;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(iaf_head_h_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * 4, st,
+                       reinterpret_cast<const unsigned*>(lin), reinterpret_cast<const unsigned*>(enc),
+                       reinterpret_cast<const unsigned*>(wpack), x, Mt, St, RS, TE, XR, T, first, tiles_per_row,
+                       ntiles);
+}

@@ -37,13 +37,15 @@ struct DeconvStackPack {
 
 // Student flow (wn_iaf.hip)
 struct IafLayerPack {
-    size_t off;                        // LAYER_FLOATS floats: P | PR | bgate | bres
+    size_t off;                        // fp32 path: LAYER_FLOATS floats: P | PR | bgate | bres
+    size_t off_h;                      // split-fp16 path: IAF_LAYER_H_WORDS words (wn_iaf_h.hip)
     int dilation;
 };
 struct IafFlowPack {
     size_t start_off;                  // w[3][W] | b[W]
     std::vector<IafLayerPack> layers;
     size_t head_off;                   // HEAD_FLOATS floats
+    size_t head_off_h;                 // split-fp16 head pack
     int deconv_stack;                  // index into wn_handle::stacks
 };
 
@@ -107,6 +109,11 @@ constexpr int IAF_LAYER_FLOATS = IAF_P_FLOATS + IAF_PR_FLOATS + 64 + 64;   // 30
 constexpr int IAF_PH_FLOATS = 80 * 4 * 64;       // 20480
 constexpr int IAF_HEAD_FLOATS = IAF_PH_FLOATS + 64 * 3 + 4;                 // 20676
 
+constexpr int IAF_LAYER_H_WORDS = IAF_P_FLOATS + IAF_PR_FLOATS + 128 + 4;   // + 1/scale_main, 1/scale_res
+// precision of the IAF contractions (wn_config.reserved[0])
+constexpr int WN_PREC_F16X3 = 0;   // split-fp16 on the fp16 MFMA (default)
+constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
+
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
 
@@ -121,9 +128,17 @@ struct DeconvScratch {
     size_t bytes;
 };
 size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F);
+// split_out: write the LAST layer's output as split-fp16 pair planes instead of fp32 rows
 int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
-                  float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st);
+                  float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st, bool split_out = false);
 
+int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
+int wn_iaf_h_set_attrs(wn_handle* h);
+void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st);
+void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
+                    int d, int B, int64_t T, int num_cu, hipStream_t st);
+void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
+                   int64_t RS, int64_t TE, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);

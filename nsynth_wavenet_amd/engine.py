@@ -23,7 +23,7 @@ class Engine(object):
     """Replaces one TF graph + Session of the reference (parallelgen.py:24-41,
     fastgen.py:139-150): built from hparams, filled with named weights."""
 
-    def __init__(self, hparams, kind=None, device=None, n_mel=80):
+    def __init__(self, hparams, kind=None, device=None, n_mel=80, precision=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('nsynth_wavenet_amd needs a ROCm GPU: the generation path has no CPU fallback')
@@ -34,7 +34,8 @@ class Engine(object):
         self._h = ctypes.c_void_p(0)
         self._ws = None
         self._finalized = False
-        c = cfg.to_wn_config(self.hp, self.kind, n_mel)
+        self.precision = precision or cfg.default_precision()
+        c = cfg.to_wn_config(self.hp, self.kind, n_mel, self.precision)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.wn_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.quant_chann = cfg.quant_chann(self.hp)
