@@ -16,6 +16,7 @@
 
 #include "wn_internal.h"
 #include "wn_codec.h"
+#include "wn_pack_h.h"
 
 
 namespace {
@@ -23,10 +24,12 @@ namespace {
 constexpr int DC_NT = 4;             // 16-column MFMA tiles per wave (dwordx4 loads)
 constexpr int DC_QT = 16 * DC_NT;    // q columns per wave
 constexpr int DC_XOFF = 8;           // zero columns left of sample 0 in every input row
+constexpr int DC_QW = 256;           // q columns per workgroup of the split-fp16 GEMM (4 waves x DC_QT)
+constexpr int DH_KC = 4;             // K-steps of weights staged in LDS per pipeline stage
 
 __host__ __device__ inline int dc_row_stride(int L) {
     // columns: [xoff zeros][L samples][zeros up to the rounded q range + slack]
-    return DC_XOFF + ((L + 2 + DC_QT - 1) / DC_QT) * DC_QT + 8;
+    return DC_XOFF + ((L + 2 + DC_QW - 1) / DC_QW) * DC_QW + 8;
 }
 
 // mel [B,F,C] (reference layout) -> channel-major padded rows [B][C][xs]
@@ -137,6 +140,121 @@ __global__ __launch_bounds__(256) void deconv_interleave_kernel(
     }
 }
 
+// mel [B,F,C] -> split-fp16 pair planes [B][2][C/2][xs] (zero padded)
+__global__ void mel_to_split_kernel(const float* __restrict__ mel, unsigned* __restrict__ out,
+                                    int F, int C, int xs) {
+    const int b = blockIdx.z, cp = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= xs) return;
+    const int f = col - DC_XOFF;
+    unsigned hw = 0, lw = 0;
+    if (f >= 0 && f < F) {
+        const float* m = mel + ((size_t)b * F + f) * C + 2 * cp;
+        wn_split_pair(m[0], m[1], hw, lw);
+    }
+    out[((size_t)b * C + cp) * xs + col] = hw;
+    out[((size_t)b * C + C / 2 + cp) * xs + col] = lw;
+}
+
+// Split-fp16 version of deconv_mfma_kernel (v_mfma_f32_16x16x32_f16, 3 MFMAs per product).
+// One workgroup = one phase r x 64 output channels x 256 q columns; wave w owns 64 of the
+// columns (4 MFMA column tiles, dwordx4 operand loads).  All four waves use the SAME weight
+// fragments, so those are staged through LDS in chunks of DH_KC K-steps (double buffered):
+// without the sharing the fp16 MFMA rate would ask the L2 for > 12 TB/s of weight reads.
+// The flattened K axis is (tap j, 16-channel block); one K-step = two consecutive blocks,
+// k-slot (kg, e) <-> channel 16*blk(e>>2) + 4*kg + (e&3) of tap j(e>>2).
+__global__ __launch_bounds__(256) void deconv_mfma_h_kernel(
+    const unsigned* __restrict__ x, int cin, int xs, const unsigned* __restrict__ wp,
+    float* __restrict__ yp, int cout, int Qp, int S, int taps, float inv_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[2][DH_KC * 4 * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kg = lane >> 4;
+    const int r = blockIdx.y;
+    const int ncg = cout / 64;
+    const int b = blockIdx.z / ncg, cg = blockIdx.z % ncg;
+    const int q0 = blockIdx.x * DC_QW + wave * DC_QT;
+    const int nmb = cout / 16;
+    const int nb16 = cin / 16;                     // 16-channel blocks per tap
+    const int nks = taps * nb16 / 2;               // K-steps of 32
+    const int nchunk = (nks + DH_KC - 1) / DH_KC;
+
+    f4 acc[4][DC_NT];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int e = 0; e < DC_NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const wn_u4* wsrc = reinterpret_cast<const wn_u4*>(wp);       // [r][ks][mb][plane][lane] u4
+    auto stage = [&](int chunk, int buf) {
+        // DH_KC K-steps x (4 row blocks x 2 planes x 64 lanes) u4 = DH_KC x 512 u4; 2 per thread per K-step
+#pragma unroll
+        for (int kl = 0; kl < DH_KC; ++kl) {
+            const int ks = chunk * DH_KC + kl;
+            if (ks < nks) {
+                const wn_u4* src = wsrc + (((size_t)r * nks + ks) * nmb + cg * 4) * 128;
+                wn_u4* dst = reinterpret_cast<wn_u4*>(lds[buf]) + kl * 512;
+                dst[threadIdx.x] = src[threadIdx.x];
+                dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+            }
+        }
+    };
+    const unsigned* xb = x + (size_t)b * cin * xs + DC_XOFF + q0 + DC_NT * n;
+    const size_t lo_plane = (size_t)(cin / 2) * xs;
+    auto loadB = [&](int ks, wn_u4 (&bh)[4], wn_u4 (&bl)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = 2 * ks + (i >> 1);               // flattened 16-channel block
+            const int j = g / nb16, blk = g - j * nb16;
+            const unsigned* p = xb + (size_t)(8 * blk + 2 * kg + (i & 1)) * xs - j;
+            bh[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p);
+            bl[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p + lo_plane);
+        }
+    };
+
+    stage(0, 0);
+    wn_u4 bh[4], bl[4];
+    loadB(0, bh, bl);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunk) stage(chunk + 1, buf ^ 1);
+        const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
+#pragma unroll
+        for (int kl = 0; kl < DH_KC; ++kl) {
+            const int ks = chunk * DH_KC + kl;
+            if (ks >= nks) break;
+            wn_u4 ch[4], cl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ch[i] = bh[i]; cl[i] = bl[i]; }
+            if (ks + 1 < nks) loadB(ks + 1, bh, bl);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const wn_u4 ah = Al[(kl * 4 + mb) * 128], al = Al[(kl * 4 + mb) * 128 + 64];
+#pragma unroll
+                for (int e = 0; e < DC_NT; ++e) {
+                    const wn_u4 vh = {ch[0][e], ch[1][e], ch[2][e], ch[3][e]};
+                    const wn_u4 vl = {cl[0][e], cl[1][e], cl[2][e], cl[3][e]};
+                    f4 c = acc[mb][e];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh), c, 0, 0, 0);
+                    acc[mb][e] = c;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = 64 * cg + 16 * mb + 4 * kg + rr;
+            float* row = yp + (((size_t)b * S + r) * cout + co) * Qp + q0 + DC_NT * n;
+            *reinterpret_cast<f4*>(row) = (f4){acc[mb][0][rr] * inv_scale, acc[mb][1][rr] * inv_scale,
+                                               acc[mb][2][rr] * inv_scale, acc[mb][3][rr] * inv_scale};
+        }
+}
+
 // channel-major [B][C][T] (row stride cs) -> reference layout [B][T][C]
 __global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict__ out,
                                 int C, int64_t T, int64_t cs) {
@@ -229,6 +347,28 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
                 }
             lp.b_off = blob.size();
             blob.insert(blob.end(), bias.begin(), bias.end());
+            // split-fp16 A fragments: [S][ks][mb][plane][lane][4], K-step = two 16-channel blocks of
+            // the flattened (tap, block) axis
+            lp.w_off_h = 0;
+            lp.inv_scale_h = 1.f;
+            if ((lp.taps * (cin / 16)) % 2 == 0 && cin % 16 == 0) {
+                const int nb16 = cin / 16, nks = lp.taps * nb16 / 2;
+                const float sc = pick_scale(W.data(), W.size());
+                lp.inv_scale_h = 1.0f / sc;
+                blob.resize(align_up(blob.size(), 64));
+                lp.w_off_h = blob.size();
+                blob.resize(blob.size() + (size_t)lp.S * nks * nmb * 512);
+                unsigned* PH = reinterpret_cast<unsigned*>(blob.data() + lp.w_off_h);
+                for (int r = 0; r < lp.S; ++r)
+                    for (int ks = 0; ks < nks; ++ks)
+                        for (int mb = 0; mb < nmb; ++mb)
+                            pack_afrag(PH + (((size_t)r * nks + ks) * nmb + mb) * 512, [&](int e, int kg, int i16) {
+                                const int g = 2 * ks + (e >> 2);
+                                const int tap = g / nb16, blk = g - tap * nb16;
+                                const int ci = 16 * blk + 4 * kg + (e & 3);
+                                return sc * W[((size_t)(lp.S * tap + r) * lp.cout + 16 * mb + i16) * cin + ci];
+                            });
+            }
             sp.layers.push_back(lp);
             cin = lp.cout;
         }
@@ -242,7 +382,7 @@ static size_t dc_phase_floats(const wn_handle* h, int B, int F) {
     size_t mx = 0;
     int64_t L = F;
     for (int j = 0; j < c.n_deconv; ++j) {
-        const size_t Qp = (size_t)((L + 2 + DC_QT - 1) / DC_QT) * DC_QT;
+        const size_t Qp = (size_t)((L + 2 + DC_QW - 1) / DC_QW) * DC_QW;
         mx = std::max(mx, (size_t)B * c.deconv_stride[j] * c.deconv_width * Qp);
         L *= c.deconv_stride[j];
     }
@@ -266,9 +406,16 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
                   int64_t enc_stride, void* scratch, hipStream_t st, bool split_out) {
     const wn_config& c = h->cfg;
     const DeconvStackPack& sp = h->stacks[si];
+    // split-fp16 GEMMs when the handle runs in f16x3 mode and every layer's shape supports them
+    bool h_gemm = c.reserved[0] == WN_PREC_F16X3;
+    for (const DeconvLayerPack& lp : sp.layers) h_gemm = h_gemm && lp.w_off_h != 0;
     float* buf = reinterpret_cast<float*>(scratch);
     int xs = dc_row_stride(F);
-    {
+    if (h_gemm) {
+        dim3 g((xs + 255) / 256, c.n_mel / 2, B);
+        hipLaunchKernelGGL(mel_to_split_kernel, g, dim3(256), 0, st, mel, reinterpret_cast<unsigned*>(buf), F,
+                           c.n_mel, xs);
+    } else {
         dim3 g((xs + 255) / 256, c.n_mel, B);
         hipLaunchKernelGGL(mel_to_cm_kernel, g, dim3(256), 0, st, mel, buf, F, c.n_mel, xs);
     }
@@ -292,12 +439,21 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
         }
         const int Q = L + 2;
-        const int Qp = ((Q + DC_QT - 1) / DC_QT) * DC_QT;
-        const int zc = (lp.cout + 255) / 256;
-        dim3 g(Qp / DC_QT, lp.S, B * zc);
-        hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off, phase,
-                           lp.cout, Qp, lp.S, lp.taps, zc);
-        if (last && split_out) {
+        const int Qp = ((Q + DC_QW - 1) / DC_QW) * DC_QW;
+        if (h_gemm) {
+            dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
+            hipLaunchKernelGGL(deconv_mfma_h_kernel, g, dim3(256), 0, st, reinterpret_cast<const unsigned*>(x),
+                               lp.cin, xs, reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h), phase, lp.cout,
+                               Qp, lp.S, lp.taps, lp.inv_scale_h);
+        } else {
+            const int zc = (lp.cout + 255) / 256;
+            dim3 g(Qp / DC_QT, lp.S, B * zc);
+            hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off, phase,
+                               lp.cout, Qp, lp.S, lp.taps, zc);
+        }
+        // intermediate outputs feed the next GEMM (split planes for the fp16 GEMM); the last one
+        // is split only when the caller consumes pair planes
+        if (last ? split_out : h_gemm) {
             dim3 gi(Qp / DC_QT, lp.cout / 2, B);
             hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
                                reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL,

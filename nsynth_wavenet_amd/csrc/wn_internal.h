@@ -27,6 +27,8 @@ struct HostTensor {
 struct DeconvLayerPack {
     int cin, cout, K, S, pL, taps;     // taps = K / S
     size_t w_off;                      // packed A fragments [S][ks4][mb][64][4]
+    size_t w_off_h;                    // split-fp16 A fragments (0 = not available for this shape)
+    float inv_scale_h;
     size_t b_off;                      // bias [cout]
 };
 
