@@ -307,6 +307,55 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
     }
 }
 
+// Last layer of the split-fp16 path: weave the phases AND emit the G4 layout of wn_iaf_h.hip
+// (4 pair rows interleaved per 16-byte word group).  One workgroup = one group (8 channels) x
+// 32 q columns = 32*S consecutive output samples, 16-byte stores.
+constexpr int DG_Q = 32;
+__global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
+    const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
+    int cout, int Qp, int64_t ys, int L, int S, int pL, int act) {
+    __shared__ float tile[8][DI_MAXS][DG_Q + 1];
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * DG_Q;
+    const int prbase = 16 * (g >> 2) + 2 * (g & 3);
+    for (int i = threadIdx.x; i < 8 * S * DG_Q; i += 256) {
+        const int c8 = i / (S * DG_Q), j = i - c8 * S * DG_Q;
+        const int r = j / DG_Q, q = j - r * DG_Q;
+        const int slot = c8 >> 1;
+        const int ch = 2 * (prbase + 8 * (slot >> 1) + (slot & 1)) + (c8 & 1);
+        tile[c8][r][q] = yp[(((size_t)b * S + r) * cout + ch) * Qp + q0 + q];
+    }
+    __syncthreads();
+    float bs[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int slot = c8 >> 1;
+        bs[c8] = bias[2 * (prbase + 8 * (slot >> 1) + (slot & 1)) + (c8 & 1)];
+    }
+    const int ng = cout / 8;
+    const int64_t SL = (int64_t)S * L;
+    wn_u4* yh = reinterpret_cast<wn_u4*>(y + ((size_t)b * cout * ys)) + (size_t)g * ys;
+    wn_u4* yl = yh + (size_t)ng * ys;
+    const int64_t n0 = (int64_t)S * q0 - pL;
+    for (int i = threadIdx.x; i < S * DG_Q; i += 256) {
+        const int q = i / S, r = i - q * S;
+        const int64_t nn = n0 + i;
+        if (nn >= 0 && nn < SL) {
+            wn_u4 hw, lw;
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                unsigned a, c2;
+                wn_split_pair(apply_act(tile[2 * slot][r][q] + bs[2 * slot], act),
+                              apply_act(tile[2 * slot + 1][r][q] + bs[2 * slot + 1], act), a, c2);
+                hw[slot] = a;
+                lw[slot] = c2;
+            }
+            yh[nn] = hw;
+            yl[nn] = lw;
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -453,7 +502,11 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         }
         // intermediate outputs feed the next GEMM (split planes for the fp16 GEMM); the last one
         // is split only when the caller consumes pair planes
-        if (last ? split_out : h_gemm) {
+        if (last && split_out) {
+            dim3 gi(Qp / DG_Q, lp.cout / 8, B);
+            hipLaunchKernelGGL(deconv_interleave_g4_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
+                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, L, lp.S, lp.pL, c.upsample_act);
+        } else if (!last && h_gemm) {
             dim3 gi(Qp / DC_QT, lp.cout / 2, B);
             hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
                                reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL,

@@ -585,8 +585,15 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     // zero left pads
     {
         dim3 g((IAF_LP + 255) / 256, B * IAF_W);
-        hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lA, L.RS, IAF_LP, B * IAF_W);
-        hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lB, L.RS, IAF_LP, B * IAF_W);
+        if (c.reserved[0] == WN_PREC_F16X3) {
+            // G4 layout: 16 interleaved group rows per batch element, each 4*(LP+T) words
+            dim3 g4((4 * IAF_LP + 255) / 256, B * 16);
+            hipLaunchKernelGGL(zero_pad_kernel, g4, dim3(256), 0, st, lA, 4 * L.RS, 4 * IAF_LP, B * 16);
+            hipLaunchKernelGGL(zero_pad_kernel, g4, dim3(256), 0, st, lB, 4 * L.RS, 4 * IAF_LP, B * 16);
+        } else {
+            hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lA, L.RS, IAF_LP, B * IAF_W);
+            hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lB, L.RS, IAF_LP, B * IAF_W);
+        }
         hipLaunchKernelGGL(zero_pad_kernel, dim3(1, B), dim3(256), 0, st, x, (int64_t)L.XR, IAF_XP, B);
     }
     // noise
@@ -635,7 +642,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         }
         for (const IafLayerPack& lp : fp.layers) {
             if (f16x3)
-                wn_iaf_h_layer(lin, lout, encc, h->d_blob + lp.off_h, L.RS, L.TE, lp.dilation, B, L.T, h->num_cu, st);
+                wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st);
             else
                 hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
                                    lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
@@ -644,7 +651,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         }
         if (h->prof_on) WN_HIP(h, hipEventRecord(h->prof_events.back(), st));
         if (f16x3)
-            wn_iaf_h_head(lin, encc, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0, B,
+            wn_iaf_h_head(lin, enc, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.TE, L.c0, L.XR, L.T, k == 0 ? 1 : 0, B,
                           h->num_cu, st);
         else
             hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,

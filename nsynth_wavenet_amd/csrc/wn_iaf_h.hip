@@ -15,6 +15,7 @@
 // residual 1x1 and the gated registers are its B operand (see wn_iaf.hip).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "wn_internal.h"
 #include "wn_codec.h"
@@ -24,8 +25,6 @@ namespace {
 
 constexpr float EXP_M9 = 1.2340980408667956e-4f;
 constexpr float EXP_7 = 1096.6331584284585f;
-constexpr int HN = 2;                         // 16-column MFMA tiles per wave (dwordx2 loads)
-constexpr int H_TILE = 64 * HN;               // samples per workgroup tile (4 waves)
 
 __device__ inline f4 mfma_h(wn_u4 a, wn_u4 b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, a), __builtin_bit_cast(wn_h8, b), c, 0, 0, 0);
@@ -60,16 +59,32 @@ __device__ inline void stage_words(const unsigned* __restrict__ wpack, unsigned*
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// "G4" activation layout of the split-fp16 path.  A lane's MFMA B operand for K-step s is
+// four words: pair rows 16s + {0,1,8,9} + 2kg.  Those four rows are stored INTERLEAVED:
+//   word(plane, group g = 4s + kg, column t, slot i)  at  ((plane*NG + g)*rowlen + t)*4 + i
+// (NG = 8 groups for the 64 residual channels, 32 for the 256 enc channels), so the operand
+// is ONE aligned 16-byte load per column -- no register shuffling between load and MFMA --
+// and the accumulator layout stores back as full 16-byte words as well (slot = 2*(mb&1)+rp
+// of group 4*(mb>>1) + kg).  Same bytes as the fp32 layout; DRAM sees 256-byte runs.
 struct HSrc {
     __amdgpu_buffer_rsrc_t rl, re;
     int vo[3];
     int ve;
 };
 
-// operand words of one K-step: rows {0,1,8,9}, hi and lo plane, HN columns each
+// operand words of one K-step: hi and lo plane, HN columns
+template <int HN>
 struct KOp {
-    wn_u2 h[4], l[4];
+    wn_u4 h[HN], l[HN];
 };
+
+__device__ inline wn_u4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
 
 // ---------------- start conv -> split l  (parallel_wavenet.py:222-225) ----------------
 __global__ void iaf_start_h_kernel(const float* __restrict__ x, const float* __restrict__ wb,
@@ -81,36 +96,47 @@ __global__ void iaf_start_h_kernel(const float* __restrict__ x, const float* __r
     float xv[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) xv[i] = xp[i - 3];
-    unsigned* hp = l + (size_t)b * IAF_W * RS + IAF_LP + t;
-    unsigned* lp = hp + (size_t)(IAF_W / 2) * RS;
-    for (int cp = 0; cp < IAF_W / 2; ++cp) {
-        float o[2][4];
+    unsigned* base = l + (size_t)b * IAF_W * RS;
+    for (int g = 0; g < 8; ++g) {
+        const int s = g >> 2, kg = g & 3;
+        wn_u4 hw[4], lw[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 2 * cp + h;
-            const float w0 = wb[c], w1 = wb[IAF_W + c], w2 = wb[2 * IAF_W + c], bb = wb[3 * IAF_W + c];
+        for (int i = 0; i < 4; ++i) {
+            const int c = 2 * (16 * s + 8 * (i >> 1) + 2 * kg + (i & 1));      // even channel of the pair
+            float o[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[h][e] = bb + w0 * xv[e] + w1 * xv[e + 1] + w2 * xv[e + 2];
+            for (int hh = 0; hh < 2; ++hh) {
+                const float w0 = wb[c + hh], w1 = wb[IAF_W + c + hh], w2 = wb[2 * IAF_W + c + hh],
+                            bb = wb[3 * IAF_W + c + hh];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[hh][e] = bb + w0 * xv[e] + w1 * xv[e + 1] + w2 * xv[e + 2];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a, c2;
+                wn_split_pair(o[0][e], o[1][e], a, c2);
+                hw[e][i] = a;
+                lw[e][i] = c2;
+            }
         }
-        wn_u4 hw, lw;
+        wn_u4* ph = reinterpret_cast<wn_u4*>(base + ((size_t)g * RS + IAF_LP + t) * 4);
+        wn_u4* pl = reinterpret_cast<wn_u4*>(base + ((size_t)(8 + g) * RS + IAF_LP + t) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsigned a, c2;
-            wn_split_pair(o[0][e], o[1][e], a, c2);
-            hw[e] = a;
-            lw[e] = c2;
+            ph[e] = hw[e];
+            pl[e] = lw[e];
         }
-        *reinterpret_cast<wn_u4*>(hp + (size_t)cp * RS) = hw;
-        *reinterpret_cast<wn_u4*>(lp + (size_t)cp * RS) = lw;
     }
 }
 
 // ---------------- fused residual layer ----------------
+template <int HN>
 __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const unsigned* __restrict__ enc,
-    const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles) {
+    const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int c0, int d, int tiles_per_row, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     stage_words<IAF_LAYER_H_WORDS>(wpack, ldsw);
+    constexpr int TILE = 64 * HN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
@@ -119,43 +145,41 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     const float* bg = ldsf + IAF_P_FLOATS + IAF_PR_FLOATS + q * 16;
     const float* br = bg + 64;
     const float inv_m = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 128], inv_r = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 129];
-    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
-    const int lane_l = (2 * q * (int)RS + wave * 16 * HN + HN * n + IAF_LP) * 4;
-    const int lane_e = (2 * q * (int)TE + wave * 16 * HN + HN * n) * 4;
+    const int RS16 = (int)RS * 16, TE16 = (int)TE * 16;                     // bytes per group row
+    const int lane_l = q * RS16 + (wave * 16 * HN + HN * n + IAF_LP) * 16;
+    const int lane_e = q * TE16 + (wave * 16 * HN + HN * n + c0) * 16;
 
     auto tile_src = [&](int tile) -> HSrc {
         const int b = tile / tiles_per_row;
-        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        const int tt = (tile - b * tiles_per_row) * TILE;
         HSrc s;
-        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
         s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
-        s.vo[0] = lane_l + (tt - 2 * d) * 4;
-        s.vo[1] = lane_l + (tt - d) * 4;
-        s.vo[2] = lane_l + tt * 4;
-        s.ve = lane_e + tt * 4;
+        s.vo[0] = lane_l + (tt - 2 * d) * 16;
+        s.vo[1] = lane_l + (tt - d) * 16;
+        s.vo[2] = lane_l + tt * 16;
+        s.ve = lane_e + tt * 16;
         return s;
     };
     // K-steps 0-5: taps t-2d, t-d, t (two 32-channel steps each); 6-13: the 256 enc channels
-    auto loadK = [&](const HSrc& s, int ks) -> KOp {
-        KOp o;
-        constexpr int rows[4] = {0, 1, 8, 9};
-        if (ks < 6) {
+    auto loadK = [&](const HSrc& s, int ks) -> KOp<HN> {
+        KOp<HN> o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.h[i] = buf_ld2(s.rl, s.vo[ks >> 1], (16 * (ks & 1) + rows[i]) * RS4);
-                o.l[i] = buf_ld2(s.rl, s.vo[ks >> 1], (32 + 16 * (ks & 1) + rows[i]) * RS4);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.h[i] = buf_ld2(s.re, s.ve, (16 * (ks - 6) + rows[i]) * TE4);
-                o.l[i] = buf_ld2(s.re, s.ve, (128 + 16 * (ks - 6) + rows[i]) * TE4);
+        for (int e = 0; e < HN; ++e) {
+            if (ks < 6) {
+                o.h[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 16 * e, (4 * (ks & 1)) * RS16);
+                o.l[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 16 * e, (8 + 4 * (ks & 1)) * RS16);
+            } else {
+                o.h[e] = buf_ld4(s.re, s.ve + 16 * e, (4 * (ks - 6)) * TE16);
+                o.l[e] = buf_ld4(s.re, s.ve + 16 * e, (32 + 4 * (ks - 6)) * TE16);
             }
         }
         return o;
     };
 
-    KOp bc[14];
+    // One-tile-ahead operand prefetch into the registers that were just consumed (see
+    // wn_iaf.hip); weights one K-step ahead from LDS into a register double buffer.
+    KOp<HN> bc[14];
     if ((int)blockIdx.x < ntiles) {
         const HSrc s0 = tile_src(blockIdx.x);
 #pragma unroll
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_row;
-        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        const int tt = (tile - b * tiles_per_row) * TILE;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         const HSrc sn = tile_src(has_next ? next : tile);
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int e = 0; e < HN; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
-        KOp cur[2];
+        KOp<HN> cur[2];
         wn_u4 a[2][4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -191,13 +215,10 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
             }
             if (ks == 4 || ks == 5) cur[ks - 4] = bc[ks];          // tap t: also the residual C-in
 #pragma unroll
-            for (int e = 0; e < HN; ++e) {
-                const wn_u4 bh = {bc[ks].h[0][e], bc[ks].h[1][e], bc[ks].h[2][e], bc[ks].h[3][e]};
-                const wn_u4 bl = {bc[ks].l[0][e], bc[ks].l[1][e], bc[ks].l[2][e], bc[ks].l[3][e]};
+            for (int e = 0; e < HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
-                    acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bh, bl, acc[mb][e]);
-            }
+                    acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 12 * HN, 0);
             if (has_next) bc[ks] = loadK(sn, ks);
@@ -205,15 +226,14 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
         }
         // epilogue per column tile: gate, residual 1x1, split, store
         const __amdgpu_buffer_rsrc_t ro =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
-        const int vo_out = lane_l + tt * 4;
+            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        const int vo_out = lane_l + tt * 16;
         wn_u4 ar[4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             ar[mb][0] = PRl[(mb * 2 + 0) * 64];
             ar[mb][1] = PRl[(mb * 2 + 1) * 64];
         }
-        unsigned oh[4][2][HN], ol[4][2][HN];
 #pragma unroll
         for (int e = 0; e < HN; ++e) {
             // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
@@ -232,30 +252,29 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 gh[i] = hw;
                 gl[i] = lw;
             }
+            wn_u4 oh[2], ol[2];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                f4 rc = mfma3(ar[mb][0], ar[mb][1], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
-                // l_old for channels 16mb+4q+r sits in K-step 4+(mb>>1), words (mb&1)*2 + (r>>1)
-                float lo_[4];
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp)
-                    wn_join_pair(cur[mb >> 1].h[(mb & 1) * 2 + rp][e], cur[mb >> 1].l[(mb & 1) * 2 + rp][e],
-                                 lo_[2 * rp], lo_[2 * rp + 1]);
+                const f4 rc = mfma3(ar[mb][0], ar[mb][1], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
-                    const float v0 = lo_[2 * rp] + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
-                    const float v1 = lo_[2 * rp + 1] + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
-                    wn_split_pair(v0, v1, oh[mb][rp][e], ol[mb][rp][e]);
+                    // l_old of channels 16mb+4q+2rp(+1): K-step 4+(mb>>1), slot 2(mb&1)+rp
+                    float l0, l1;
+                    wn_join_pair(cur[mb >> 1].h[e][(mb & 1) * 2 + rp], cur[mb >> 1].l[e][(mb & 1) * 2 + rp], l0, l1);
+                    const float v0 = l0 + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
+                    const float v1 = l1 + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
+                    unsigned hw, lw;
+                    wn_split_pair(v0, v1, hw, lw);
+                    oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
+                    ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
                 }
             }
-        }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int rp = 0; rp < 2; ++rp) {
-                buf_st2(oh[mb][rp][0], oh[mb][rp][1], ro, vo_out, (8 * mb + rp) * RS4);
-                buf_st2(ol[mb][rp][0], ol[mb][rp][1], ro, vo_out, (32 + 8 * mb + rp) * RS4);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                buf_st4(oh[s2], ro, vo_out + 16 * e, (4 * s2) * RS16);
+                buf_st4(ol[s2], ro, vo_out + 16 * e, (8 + 4 * s2) * RS16);
             }
+        }
     }
 }
 
@@ -267,12 +286,14 @@ __device__ inline float softplus_tf(float p) {
     return log1pf(expf(p));
 }
 
+template <int HN>
 __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
     const unsigned* __restrict__ lin, const unsigned* __restrict__ enc, const unsigned* __restrict__ wpack,
     float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
-    int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
+    int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     stage_words<IAF_HEAD_FLOATS>(wpack, ldsw);
+    constexpr int TILE = 64 * HN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;
@@ -282,40 +303,36 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
     const float* wsc = wm + 64;
     const float bmean = ldsf[IAF_PH_FLOATS + 192], bscale = ldsf[IAF_PH_FLOATS + 193];
     const float inv_m = ldsf[IAF_PH_FLOATS + 194];
-    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
-    const int lane_l = (2 * q * (int)RS + wave * 16 * HN + HN * n + IAF_LP) * 4;
-    const int lane_e = (2 * q * (int)TE + wave * 16 * HN + HN * n) * 4;
+    const int RS16 = (int)RS * 16, TE16 = (int)TE * 16;
+    const int lane_l = q * RS16 + (wave * 16 * HN + HN * n + IAF_LP) * 16;
+    const int lane_e = q * TE16 + (wave * 16 * HN + HN * n + c0) * 16;
 
     auto tile_src = [&](int tile) -> HSrc {
         const int b = tile / tiles_per_row;
-        const int tt = (tile - b * tiles_per_row) * H_TILE;
+        const int tt = (tile - b * tiles_per_row) * TILE;
         HSrc s;
-        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
         s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
-        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 4;
-        s.ve = lane_e + tt * 4;
+        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 16;
+        s.ve = lane_e + tt * 16;
         return s;
     };
     // K-steps 0-1: out1 over relu(l); 2-9: mel_cond_out1 over the 256 enc channels
-    auto loadK = [&](const HSrc& s, int ks) -> KOp {
-        KOp o;
-        constexpr int rows[4] = {0, 1, 8, 9};
-        if (ks < 2) {
+    auto loadK = [&](const HSrc& s, int ks) -> KOp<HN> {
+        KOp<HN> o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.h[i] = buf_ld2(s.rl, s.vo[2], (16 * ks + rows[i]) * RS4);
-                o.l[i] = buf_ld2(s.rl, s.vo[2], (32 + 16 * ks + rows[i]) * RS4);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.h[i] = buf_ld2(s.re, s.ve, (16 * (ks - 2) + rows[i]) * TE4);
-                o.l[i] = buf_ld2(s.re, s.ve, (128 + 16 * (ks - 2) + rows[i]) * TE4);
+        for (int e = 0; e < HN; ++e) {
+            if (ks < 2) {
+                o.h[e] = buf_ld4(s.rl, s.vo[2] + 16 * e, (4 * ks) * RS16);
+                o.l[e] = buf_ld4(s.rl, s.vo[2] + 16 * e, (8 + 4 * ks) * RS16);
+            } else {
+                o.h[e] = buf_ld4(s.re, s.ve + 16 * e, (4 * (ks - 2)) * TE16);
+                o.l[e] = buf_ld4(s.re, s.ve + 16 * e, (32 + 4 * (ks - 2)) * TE16);
             }
         }
         return o;
     };
-    KOp bc[10];
+    KOp<HN> bc[10];
     if ((int)blockIdx.x < ntiles) {
         const HSrc s0 = tile_src(blockIdx.x);
 #pragma unroll
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_row;
-        const int t0 = (tile - b * tiles_per_row) * H_TILE + wave * 16 * HN;
+        const int t0 = (tile - b * tiles_per_row) * TILE + wave * 16 * HN;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         const HSrc sn = tile_src(has_next ? next : tile);
@@ -349,8 +366,7 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
             }
 #pragma unroll
             for (int e = 0; e < HN; ++e) {
-                wn_u4 bh = {bc[ks].h[0][e], bc[ks].h[1][e], bc[ks].h[2][e], bc[ks].h[3][e]};
-                wn_u4 bl = {bc[ks].l[0][e], bc[ks].l[1][e], bc[ks].l[2][e], bc[ks].l[3][e]};
+                wn_u4 bh = bc[ks].h[e], bl = bc[ks].l[e];
                 if (ks < 2) {                         // relu(l) (:256) on the reconstructed value
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -487,9 +503,13 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
 }
 
 int wn_iaf_h_set_attrs(wn_handle* h) {
-    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel),
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_H_WORDS * 4));
-    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_h_kernel),
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_H_WORDS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_h_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_h_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * 4));
     return WN_OK;
 }
@@ -499,22 +519,36 @@ void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR
     hipLaunchKernelGGL(iaf_start_h_kernel, g, dim3(256), 0, st, x, wb, reinterpret_cast<unsigned*>(l), T, XR, RS);
 }
 
+// 64- or 128-sample workgroup tiles: whichever leaves the last round of the persistent grid
+// fuller (B*T/64 tiles over num_cu workgroups); 128 halves the LDS weight traffic per sample.
+static int pick_hn(int B, int64_t T, int num_cu) {
+    const int64_t n1 = B * (T / 64), n2 = B * (T / 128);
+    const int64_t c1 = (n1 + num_cu - 1) / num_cu, c2 = 2 * ((n2 + num_cu - 1) / num_cu);
+    const char* force = getenv("WN_HN");
+    if (force) return atoi(force) == 1 ? 1 : 2;
+    return c1 < c2 ? 1 : 2;
+}
+
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int d, int B, int64_t T, int num_cu, hipStream_t st) {
-    const int tiles_per_row = (int)(T / H_TILE), ntiles = B * tiles_per_row;
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st) {
+    const int hn = pick_hn(B, T, num_cu);
+    const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(iaf_layer_h_kernel, dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st,
+    auto kern = hn == 1 ? iaf_layer_h_kernel<1> : iaf_layer_h_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st,
                        reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout),
-                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wpack), RS, TE, d,
+                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wpack), RS, TE, c0, d,
                        tiles_per_row, ntiles);
 }
 
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
-                   int64_t RS, int64_t TE, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st) {
-    const int tiles_per_row = (int)(T / H_TILE), ntiles = B * tiles_per_row;
+                   int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st) {
+    const int hn = pick_hn(B, T, num_cu);
+    const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(iaf_head_h_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * 4, st,
+    auto kern = hn == 1 ? iaf_head_h_kernel<1> : iaf_head_h_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), IAF_HEAD_FLOATS * 4, st,
                        reinterpret_cast<const unsigned*>(lin), reinterpret_cast<const unsigned*>(enc),
-                       reinterpret_cast<const unsigned*>(wpack), x, Mt, St, RS, TE, XR, T, first, tiles_per_row,
+                       reinterpret_cast<const unsigned*>(wpack), x, Mt, St, RS, TE, c0, XR, T, first, tiles_per_row,
                        ntiles);
 }

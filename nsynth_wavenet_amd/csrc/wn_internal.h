@@ -130,7 +130,8 @@ struct DeconvScratch {
     size_t bytes;
 };
 size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F);
-// split_out: write the LAST layer's output as split-fp16 pair planes instead of fp32 rows
+// split_out: write the LAST layer's output as split-fp16 words in the G4 layout (wn_iaf_h.hip)
+// instead of fp32 rows
 int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
                   float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st, bool split_out = false);
 
@@ -138,9 +139,9 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
 int wn_iaf_h_set_attrs(wn_handle* h);
 void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st);
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int d, int B, int64_t T, int num_cu, hipStream_t st);
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st);
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
-                   int64_t RS, int64_t TE, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
+                   int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);
