@@ -36,22 +36,23 @@ LAYER_BYTES_PER_SAMPLE = 1536          # read l 256 B + read mel_en 1024 B + wri
 PATH_FLOP_PER_SAMPLE = 4385280
 PATH_BYTES_PER_SAMPLE = 98484
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
-def pmc_traffic(B, F):
+def pmc_traffic(B, F, precision='f16x3'):
     """HBM bytes per iaf_layer_kernel launch from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
     PMC counters cannot be collected from inside this process, so this is the value of the
     profiled run of the SAME command; None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json' if precision == 'f32' else 'r01_pmc_summary_f16x3.json')
     try:
         with open(path) as f:
             d = json.load(f)
         w = d['workload']
         if (w['batch_per_gpu'], w['frames']) != (B, F):
             return None
-        return d['kernels']['iaf_layer_kernel']['hbm_bytes_per_launch']
+        return d['kernels']['iaf_layer_kernel' if precision == 'f32' else 'iaf_layer_h_kernel']['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
@@ -110,6 +111,8 @@ def main():
     ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'f32'],
+                    help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     args = ap.parse_args()
 
     rank, world, local = wdist.env_rank_world()
@@ -130,7 +133,7 @@ def main():
     # builds them, every other rank receives them in one RCCL broadcast over xGMI
     weights = wts.synthetic_weights(hp, 'student', seed=1234, init='tf') if rank == 0 else None
     weights = wdist.broadcast_weights(weights, hp, 'student', src=0, device=dev)
-    eng = Engine(hp, kind='student', device=dev).load_weights(weights)
+    eng = Engine(hp, kind='student', device=dev, precision=args.precision).load_weights(weights)
 
     B, F = args.batch_per_gpu, args.frames
     T = eng.iaf_length(F)
@@ -167,7 +170,29 @@ def main():
         value = total_samples / elapsed
         avg_layer_s = layer_ms * 1e-3 / max(layer_launches, 1)
         flops_per_launch = LAYER_FLOP_PER_SAMPLE * B * T
+        bytes_per_launch = LAYER_BYTES_PER_SAMPLE * B * T
         achieved_tf = flops_per_launch / avg_layer_s / 1e12
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        if eng.precision == 'f16x3':
+            # split-fp16 operands on the fp16 MFMA: 3 MFMAs per product -> the matrix pipe needs
+            # 3*61440 fp16-FLOP/sample at a 2.5 PFLOP/s peak (0.07 ns) vs 1536 B/sample at 8 TB/s
+            # (0.19 ns): the kernel is HBM-bound
+            roof = {'kernel': 'iaf_layer_h_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, split-fp16 MFMA)',
+                    'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                    'frac': achieved_gbps / PEAK_HBM_GBPS,
+                    'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS,
+                                  'algorithmic_TFLOPs': achieved_tf}}
+            dtype = 'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
+        else:
+            roof = {'kernel': 'iaf_layer_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, fp32 MFMA)',
+                    'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                    'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
+            dtype = 'f32'
+        roof.update({'traffic': pmc_traffic(B, F, eng.precision),
+                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
+                     'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
+                     'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
         rec = {
             'metric': '16 kHz audio samples/sec, parallel-WaveNet (IAF student) generation',
             'value': value,
@@ -179,7 +204,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': dtype,
             'data': 'synthetic',
             'config': {
                 'workload': 'BASELINE.json configs[1]: parallel_wavenet.json IAF student generation, '
@@ -189,27 +214,13 @@ def main():
                 'x_realtime_per_gpu': value / world / 16000.0,
                 'samples_per_sec_per_gpu': value / world,
                 'weights': 'random-init (TF initialisers), seed 1234; noise drawn on device (Philox)',
+                'precision': eng.precision,
                 'parallelism': 'utterance-sharded x{} (no data-path collective)'.format(world),
                 'path_gflop_per_step_per_gpu': PATH_FLOP_PER_SAMPLE * B * T / 1e9,
                 'path_achieved_tflops': PATH_FLOP_PER_SAMPLE * (total_samples / world) / elapsed / 1e12,
                 'path_algorithmic_GBps': PATH_BYTES_PER_SAMPLE * (total_samples / world) / elapsed / 1e9,
             },
-            'roofline': {
-                'kernel': 'iaf_layer_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1)',
-                'bound': 'mfma',
-                'achieved': achieved_tf,
-                'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                'traffic': pmc_traffic(B, F),
-                'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)',
-                'algorithmic_bytes_per_launch': LAYER_BYTES_PER_SAMPLE * B * T,
-                'avg_launch_us': avg_layer_s * 1e6,
-                'launches': layer_launches,
-                'flop_per_launch': flops_per_launch,
-                'hbm_view': {'algorithmic_GBps': LAYER_BYTES_PER_SAMPLE * B * T / avg_layer_s / 1e9,
-                             'peak_GBps': PEAK_HBM_GBPS},
-            },
+            'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(hp_dict, F)

@@ -16,24 +16,27 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def _engine(cfgd, weights):
+def _engine(cfgd, weights, precision=None):
     from nsynth_wavenet_amd.engine import Engine
-    return Engine(cfgd).load_weights(weights)
+    return Engine(cfgd, precision=precision).load_weights(weights)
 
 
 def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('tag', ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'])
-def test_golden_vectors(tag):
+def test_golden_vectors(tag, precision):
     """HIP path vs the committed oracle vectors (shared deconv + centre crop 76; unit-gain
-    stress weights; ClariNet config with four private deconv stacks; mu-law student)."""
+    stress weights; ClariNet config with four private deconv stacks; mu-law student), for both
+    contraction arithmetics: split-fp16 x3 on the fp16 MFMA (default) and plain fp32 MFMA."""
     from oracle import wavenet_np as O
     g = np.load(os.path.join(GOLD, tag + '.npz'))
     cfgd = json.loads(str(g['cfg_json']))
     w = O.synth_weights(O.HP(cfgd), 'student', seed=int(g['seed']), init=str(g['init']))
-    eng = _engine(cfgd, w)
+    eng = _engine(cfgd, w, precision)
+    assert eng.precision == precision
     out = eng.iaf_generate(g['mel'], g['noise'], want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot', 'rand_input'))
     scale = max(1.0, float(np.abs(g['x']).max()))
     assert np.abs(_np(out['x']) - g['x']).max() <= 2e-5 * scale
@@ -254,3 +257,26 @@ def test_reference_interface_mirror(tmp_path):
     assert sorted(os.listdir(str(out))) == ['gen_utt1.wav', 'gen_utt2.wav']
     sr, a = wavfile.read(str(out / 'gen_utt1.wav'))
     assert sr == 16000 and a.dtype == np.float32 and a.shape == (2048,)
+
+
+def test_split_fp16_is_as_accurate_as_fp32():
+    """The default arithmetic (split-fp16 operands, 3 fp16 MFMAs per product, fp32 accumulate)
+    must not be a precision downgrade: against the float64 oracle its error is within 2x of the
+    fp32-MFMA path's error on the same inputs, on both weight sets, at a non-trivial length."""
+    from oracle import wavenet_np as O
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    rs = np.random.RandomState(4)
+    mel = rs.uniform(0, 1, [1, 21, 80]).astype(np.float32)          # T = 4096, crop 52
+    noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [1, 4096]))
+    for init in ('tf', 'unit'):
+        w = O.synth_weights(hp, 'student', seed=1234, init=init)
+        ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)['x']
+        err = {}
+        for prec in ('f16x3', 'f32'):
+            eng = _engine(cfgd, w, prec)
+            err[prec] = np.abs(_np(eng.iaf_generate(mel, noise, want=('x',))['x']) - ref).max()
+            eng.close()
+        scale = max(1.0, np.abs(ref).max())
+        assert err['f16x3'] <= 2e-5 * scale and err['f32'] <= 2e-5 * scale, (init, err)
+        assert err['f16x3'] <= 2.0 * err['f32'] + 1e-7 * scale, (init, err)
