@@ -166,18 +166,21 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
 }
 
 // ---- dilated causal_linear + conditioning + gate (wavenet.py:456-479, masked.py:369-376) ----
-// one wave = gate pair (o, o+m): x = [ring[t-2d] | ring[t-d] | l | enc_t], K = 3W + Cd
+// one WORKGROUP = gate pair (o, o+m); its four waves split K = 3W + Cd in quarters (at batch 1
+// the kernel is one memory round trip long, so the only lever is more, smaller waves), partial
+// sums meet in LDS.  x = [ring[t-2d] | ring[t-d] | l | enc_t]
 __global__ __launch_bounds__(256) void ar_gate_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Wm,
     const float* __restrict__ bias, const float* __restrict__ enc, int Tn, int per_step, size_t ring_off,
     int dil) {
-    const int lane = threadIdx.x & 63;
+    __shared__ float part[4][AR_BT][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = D.G / 2;
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (o >= m) return;
+    const int o = blockIdx.x;
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
-    const int K = 3 * D.W + D.Cd;
+    const int K = 3 * D.W + D.Cd, KQ = K / 4;
+    const int k0 = wave * KQ, k1 = k0 + KQ;
     const float* w0 = Wm + (size_t)o * K;
     const float* w1 = Wm + (size_t)(o + m) * K;
     const float* ring = state + L.rings + (size_t)D.B * ring_off;
@@ -193,13 +196,13 @@ __global__ __launch_bounds__(256) void ar_gate_kernel(
         float a0[AR_BT], a1[AR_BT];
 #pragma unroll
         for (int e = 0; e < AR_BT; ++e) a0[e] = a1[e] = 0.f;
-        for (int kc = 0; kc < K; kc += AR_KC * 256) {
+        for (int kc = k0; kc < k1; kc += AR_KC * 256) {
             f4 wa[AR_KC], wb[AR_KC];
 #pragma unroll
             for (int i = 0; i < AR_KC; ++i) {
                 const int k = kc + i * 256 + lane * 4;
-                wa[i] = k < K ? *reinterpret_cast<const f4*>(w0 + k) : (f4){0.f, 0.f, 0.f, 0.f};
-                wb[i] = k < K ? *reinterpret_cast<const f4*>(w1 + k) : (f4){0.f, 0.f, 0.f, 0.f};
+                wa[i] = k < k1 ? *reinterpret_cast<const f4*>(w0 + k) : (f4){0.f, 0.f, 0.f, 0.f};
+                wb[i] = k < k1 ? *reinterpret_cast<const f4*>(w1 + k) : (f4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int e = 0; e < AR_BT; ++e) {
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void ar_gate_kernel(
 #pragma unroll
                 for (int i = 0; i < AR_KC; ++i) {
                     const int k = kc + i * 256 + lane * 4;
-                    xv[i] = k < K ? *reinterpret_cast<const f4*>(xptr(b, k)) : (f4){0.f, 0.f, 0.f, 0.f};
+                    xv[i] = k < k1 ? *reinterpret_cast<const f4*>(xptr(b, k)) : (f4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int i = 0; i < AR_KC; ++i) {
@@ -220,13 +223,17 @@ __global__ __launch_bounds__(256) void ar_gate_kernel(
         }
 #pragma unroll
         for (int e = 0; e < AR_BT; ++e) {
-            const int b = b0 + e;
-            if (b >= D.B) break;
-            const float hs = wave_sum(a0[e]) + bias[o];
-            const float ht = wave_sum(a1[e]) + bias[o + m];
-            if (lane == 0)
-                state[L.g + (size_t)b * m + o] = (1.f / (1.f + expf(-hs))) * tanhf(ht);   // wavenet.py:479
+            const float s0 = wave_sum(a0[e]), s1 = wave_sum(a1[e]);
+            if (lane == 0) { part[wave][e][0] = s0; part[wave][e][1] = s1; }
         }
+        __syncthreads();
+        if (threadIdx.x < AR_BT && b0 + (int)threadIdx.x < D.B) {
+            const int e = threadIdx.x;
+            const float hs = part[0][e][0] + part[1][e][0] + part[2][e][0] + part[3][e][0] + bias[o];
+            const float ht = part[0][e][1] + part[1][e][1] + part[2][e][1] + part[3][e][1] + bias[o + m];
+            state[L.g + (size_t)(b0 + e) * m + o] = (1.f / (1.f + expf(-hs))) * tanhf(ht);   // wavenet.py:479
+        }
+        __syncthreads();
     }
 }
 
@@ -339,7 +346,7 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
     hipLaunchKernelGGL(ar_rows_kernel<0>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wss_off,
                        blob + P.bss_off, D.S, D.W, enc, Tn, per_step, (size_t)0, 1);
     for (const ArLayerPack& lp : P.layers) {
-        hipLaunchKernelGGL(ar_gate_kernel, dim3((D.G / 2 + 3) / 4), dim3(256), 0, st, state, L, D,
+        hipLaunchKernelGGL(ar_gate_kernel, dim3(D.G / 2), dim3(256), 0, st, state, L, D,
                            blob + lp.wd_off, blob + lp.bd_off, enc, Tn, per_step, lp.ring_off, lp.dilation);
         hipLaunchKernelGGL(ar_rows_kernel<1>, dim3((D.W + D.S + 3) / 4), dim3(256), 0, st, state, L, D,
                            blob + lp.wrs_off, blob + lp.brs_off, D.W + D.S, D.G / 2, enc, Tn, per_step,
