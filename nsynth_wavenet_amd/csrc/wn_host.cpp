@@ -279,3 +279,33 @@ std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, c
             }
     return W;
 }
+
+// ---- CRC32C (Castagnoli) for the TensorFlow checkpoint reader/writer (tf_bundle.py) ----
+// Internal helper, not part of wnhip.h: slicing-by-8 table lookup on the host.
+extern "C" uint32_t wnx_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+        init = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = crc ^ 0xffffffffu;
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        v ^= c;
+        c = T[7][v & 0xff] ^ T[6][(v >> 8) & 0xff] ^ T[5][(v >> 16) & 0xff] ^ T[4][(v >> 24) & 0xff] ^
+            T[3][(v >> 32) & 0xff] ^ T[2][(v >> 40) & 0xff] ^ T[1][(v >> 48) & 0xff] ^ T[0][(v >> 56) & 0xff];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}

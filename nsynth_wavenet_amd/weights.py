@@ -4,8 +4,9 @@ The reference restores  '<var>/ExponentialMovingAverage' -> var  for every
 trainable variable (wavenet/fastgen.py:12-14), except that with
 `use_teacher_deconv` the teacher-owned 'iaf_share/trans_conv_*' variables are
 read under their raw names (wavenet/parallelgen.py:29-41).  TensorFlow V2
-checkpoint bundles cannot be parsed here yet; the
-on-disk format of this package is an `.npz` holding exactly those keys.
+checkpoint bundles are read by tf_bundle.py (validated only
+against its own writer: no TF-written file is available offline); the package's
+own on-disk format is an `.npz` holding exactly the same keys.
 """
 import glob
 import os
@@ -122,11 +123,28 @@ def save_checkpoint(path, weights, hp=None, ema=True):
     return path if path.endswith('.npz') else path + '.npz'
 
 
+class _BundleView(object):
+    """np.load-like view (files, []) over a TensorFlow V2 checkpoint prefix."""
+
+    def __init__(self, prefix):
+        from . import tf_bundle
+        self._r = tf_bundle.BundleReader(prefix)
+        self.files = list(self._r.entries)
+
+    def __getitem__(self, key):
+        return self._r.get_tensor(key)
+
+
 def load_checkpoint(path, hp, kind=None):
-    """name -> float32 array for every variable of `hp`; EMA shadow preferred."""
-    if not path.endswith('.npz') and os.path.exists(path + '.npz'):
-        path = path + '.npz'
-    blob = np.load(path)
+    """name -> float32 array for every variable of `hp`; EMA shadow preferred.  `path` is either
+    an .npz written by save_checkpoint or a TensorFlow V2 checkpoint prefix
+    (`model.ckpt-N` with `.index` / `.data-00000-of-00001` next to it, read by tf_bundle)."""
+    if os.path.exists(path + '.index'):
+        blob = _BundleView(path)
+    else:
+        if not path.endswith('.npz') and os.path.exists(path + '.npz'):
+            path = path + '.npz'
+        blob = np.load(path)
     out = {}
     missing = []
     for name, shape in expected_variables(hp, kind):
@@ -155,13 +173,14 @@ def latest_checkpoint(ckpt_dir):
         if m:
             p = m.group(1)
             p = p if os.path.isabs(p) else os.path.join(ckpt_dir, p)
-            if os.path.exists(p) or os.path.exists(p + '.npz'):
+            if os.path.exists(p) or os.path.exists(p + '.npz') or os.path.exists(p + '.index'):
                 return p
     best, best_n = None, -1
-    for p in glob.glob(os.path.join(ckpt_dir, 'model.ckpt-*.npz')):
-        m = re.search(r'model\.ckpt-(\d+)\.npz$', p)
+    for p in glob.glob(os.path.join(ckpt_dir, 'model.ckpt-*.npz')) + glob.glob(os.path.join(ckpt_dir, 'model.ckpt-*.index')):
+        m = re.search(r'model\.ckpt-(\d+)\.(npz|index)$', p)      # run_all_eval.py:36-49 uses the same pattern
         if m and int(m.group(1)) > best_n:
-            best, best_n = p, int(m.group(1))
+            best_n = int(m.group(1))
+            best = p if p.endswith('.npz') else p[:-len('.index')]
     if best is None:
         cands = sorted(glob.glob(os.path.join(ckpt_dir, '*.npz')))
         best = cands[-1] if cands else None
