@@ -556,6 +556,9 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     if (ws_bytes < L.total)
         return wn_fail(h, WN_ENOMEM, "wn_iaf_generate: workspace %zu < %zu bytes", ws_bytes, L.total);
     if ((int64_t)B * L.T / 64 > 0x7fffffff) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: batch too large");
+    if (L.TE > 2000000)   // 32-bit buffer offsets inside one batch element (960 * TE bytes)
+        return wn_fail(h, WN_EINVAL, "wn_iaf_generate: %lld samples per utterance exceeds the 2,000,000 "
+                       "(125 s) limit of the 32-bit row offsets; split the utterance", (long long)L.TE);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* base = reinterpret_cast<char*>(ws);
     float* enc = reinterpret_cast<float*>(base + L.enc);

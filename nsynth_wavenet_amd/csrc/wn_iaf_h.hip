@@ -106,46 +106,32 @@ __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int 
 }
 
 // ---------------- start conv -> split l  (parallel_wavenet.py:222-225) ----------------
-__global__ void iaf_start_h_kernel(const float* __restrict__ x, const float* __restrict__ wb,
-                                   unsigned* __restrict__ l, int64_t T, int XR, int64_t RS) {
-    const int b = blockIdx.y;
-    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// One thread = one G4 word group (8 channels) at one time step: consecutive threads write
+// consecutive 16-byte words of a group row (fully coalesced hi and lo streams).
+__global__ __launch_bounds__(256) void iaf_start_h_kernel(const float* __restrict__ x, const float* __restrict__ wb,
+                                                          unsigned* __restrict__ l, int64_t T, int XR, int64_t RS) {
+    const int b = blockIdx.z, g = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const float* xp = x + (size_t)b * XR + IAF_XP + t;
-    float xv[7];
+    const float x0 = xp[-3], x1 = xp[-2], x2 = xp[-1];
+    const int s = g >> 2, kg = g & 3;
+    wn_u4 hw, lw;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) xv[i] = xp[i - 3];
-    unsigned* base = l + (size_t)b * IAF_W * RS;
-    for (int g = 0; g < 8; ++g) {
-        const int s = g >> 2, kg = g & 3;
-        wn_u4 hw[4], lw[4];
+    for (int i = 0; i < 4; ++i) {
+        const int c = 2 * (16 * s + 8 * (i >> 1) + 2 * kg + (i & 1));      // even channel of the pair
+        float o[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 2 * (16 * s + 8 * (i >> 1) + 2 * kg + (i & 1));      // even channel of the pair
-            float o[2][4];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const float w0 = wb[c + hh], w1 = wb[IAF_W + c + hh], w2 = wb[2 * IAF_W + c + hh],
-                            bb = wb[3 * IAF_W + c + hh];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[hh][e] = bb + w0 * xv[e] + w1 * xv[e + 1] + w2 * xv[e + 2];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned a, c2;
-                wn_split_pair(o[0][e], o[1][e], a, c2);
-                hw[e][i] = a;
-                lw[e][i] = c2;
-            }
-        }
-        wn_u4* ph = reinterpret_cast<wn_u4*>(base + ((size_t)g * RS + IAF_LP + t) * 4);
-        wn_u4* pl = reinterpret_cast<wn_u4*>(base + ((size_t)(8 + g) * RS + IAF_LP + t) * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ph[e] = hw[e];
-            pl[e] = lw[e];
-        }
+        for (int hh = 0; hh < 2; ++hh)
+            o[hh] = wb[3 * IAF_W + c + hh] + wb[c + hh] * x0 + wb[IAF_W + c + hh] * x1 + wb[2 * IAF_W + c + hh] * x2;
+        unsigned a, c2;
+        wn_split_pair(o[0], o[1], a, c2);
+        hw[i] = a;
+        lw[i] = c2;
     }
+    unsigned* base = l + (size_t)b * IAF_W * RS;
+    *reinterpret_cast<wn_u4*>(base + ((size_t)g * RS + IAF_LP + t) * 4) = hw;
+    *reinterpret_cast<wn_u4*>(base + ((size_t)(8 + g) * RS + IAF_LP + t) * 4) = lw;
 }
 
 // ---------------- fused residual layer ----------------
@@ -539,7 +525,7 @@ int wn_iaf_h_set_attrs(wn_handle* h) {
 }
 
 void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st) {
-    dim3 g((unsigned)((T / 4 + 255) / 256), B);
+    dim3 g((unsigned)((T + 255) / 256), 8, B);
     hipLaunchKernelGGL(iaf_start_h_kernel, g, dim3(256), 0, st, x, wb, reinterpret_cast<unsigned*>(l), T, XR, RS);
 }
 
