@@ -163,7 +163,11 @@ __global__ void mel_to_split_kernel(const float* __restrict__ mel, unsigned* __r
 // without the sharing the fp16 MFMA rate would ask the L2 for > 12 TB/s of weight reads.
 // The flattened K axis is (tap j, 16-channel block); one K-step = two consecutive blocks,
 // k-slot (kg, e) <-> channel 16*blk(e>>2) + 4*kg + (e&3) of tap j(e>>2).
-__global__ __launch_bounds__(256) void deconv_mfma_h_kernel(
+// G4IN: the input is in the 4-row-interleaved G4 layout (needs cin % 32 == 0, so that both
+// 16-channel blocks of a K-step belong to one tap): one 16-byte load per column is the whole
+// operand, no register transposes.  Otherwise planar pair planes (mel, cin = 80).
+template <bool G4IN>
+__global__ __launch_bounds__(256, 2) void deconv_mfma_h_kernel(
     const unsigned* __restrict__ x, int cin, int xs, const unsigned* __restrict__ wp,
     float* __restrict__ yp, int cout, int Qp, int S, int taps, float inv_scale) {
     __shared__ __attribute__((aligned(16))) unsigned lds[2][DH_KC * 4 * 512];
@@ -198,22 +202,40 @@ __global__ __launch_bounds__(256) void deconv_mfma_h_kernel(
             }
         }
     };
-    const unsigned* xb = x + (size_t)b * cin * xs + DC_XOFF + q0 + DC_NT * n;
+    const unsigned* xb = x + (size_t)b * cin * xs;
     const size_t lo_plane = (size_t)(cin / 2) * xs;
-    auto loadB = [&](int ks, wn_u4 (&bh)[4], wn_u4 (&bl)[4]) {
+    // operand words of K-step ks for the DC_NT columns of this lane: vh[e], vl[e]
+    auto loadB = [&](int ks, wn_u4 (&vh)[DC_NT], wn_u4 (&vl)[DC_NT]) {
+        if (G4IN) {
+            const int nb32 = cin / 32;
+            const int j = ks / nb32, c = ks - j * nb32;
+            const unsigned* p = xb + ((size_t)(4 * c + kg) * xs + DC_XOFF + q0 + DC_NT * n - j) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = 2 * ks + (i >> 1);               // flattened 16-channel block
-            const int j = g / nb16, blk = g - j * nb16;
-            const unsigned* p = xb + (size_t)(8 * blk + 2 * kg + (i & 1)) * xs - j;
-            bh[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p);
-            bl[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p + lo_plane);
+            for (int e = 0; e < DC_NT; ++e) {
+                vh[e] = *reinterpret_cast<const wn_u4*>(p + 4 * e);
+                vl[e] = *reinterpret_cast<const wn_u4*>(p + lo_plane + 4 * e);
+            }
+        } else {
+            wn_u4 bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = 2 * ks + (i >> 1);               // flattened 16-channel block
+                const int j = g / nb16, blk = g - j * nb16;
+                const unsigned* p = xb + (size_t)(8 * blk + 2 * kg + (i & 1)) * xs + DC_XOFF + q0 + DC_NT * n - j;
+                bh[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p);
+                bl[i] = *reinterpret_cast<const wn_u4 __attribute__((aligned(4)))*>(p + lo_plane);
+            }
+#pragma unroll
+            for (int e = 0; e < DC_NT; ++e) {
+                vh[e] = (wn_u4){bh[0][e], bh[1][e], bh[2][e], bh[3][e]};
+                vl[e] = (wn_u4){bl[0][e], bl[1][e], bl[2][e], bl[3][e]};
+            }
         }
     };
 
     stage(0, 0);
-    wn_u4 bh[4], bl[4];
-    loadB(0, bh, bl);
+    wn_u4 b1h[DC_NT], b1l[DC_NT];      // operands one K-step ahead (two waves per SIMD hide the rest)
+    loadB(0, b1h, b1l);
     __syncthreads();
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const int buf = chunk & 1;
@@ -223,21 +245,19 @@ __global__ __launch_bounds__(256) void deconv_mfma_h_kernel(
         for (int kl = 0; kl < DH_KC; ++kl) {
             const int ks = chunk * DH_KC + kl;
             if (ks >= nks) break;
-            wn_u4 ch[4], cl[4];
+            wn_u4 vh[DC_NT], vl[DC_NT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ch[i] = bh[i]; cl[i] = bl[i]; }
-            if (ks + 1 < nks) loadB(ks + 1, bh, bl);
+            for (int e = 0; e < DC_NT; ++e) { vh[e] = b1h[e]; vl[e] = b1l[e]; }
+            if (ks + 1 < nks) loadB(ks + 1, b1h, b1l);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const wn_u4 ah = Al[(kl * 4 + mb) * 128], al = Al[(kl * 4 + mb) * 128 + 64];
 #pragma unroll
                 for (int e = 0; e < DC_NT; ++e) {
-                    const wn_u4 vh = {ch[0][e], ch[1][e], ch[2][e], ch[3][e]};
-                    const wn_u4 vl = {cl[0][e], cl[1][e], cl[2][e], cl[3][e]};
                     f4 c = acc[mb][e];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh[e]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), c, 0, 0, 0);
                     acc[mb][e] = c;
                 }
             }
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
 constexpr int DG_Q = 32;
 __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
-    int cout, int Qp, int64_t ys, int L, int S, int pL, int act) {
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act) {
     __shared__ float tile[8][DI_MAXS][DG_Q + 1];
     const int g = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * DG_Q;
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     }
     const int ng = cout / 8;
     const int64_t SL = (int64_t)S * L;
-    wn_u4* yh = reinterpret_cast<wn_u4*>(y + ((size_t)b * cout * ys)) + (size_t)g * ys;
+    wn_u4* yh = reinterpret_cast<wn_u4*>(y + ((size_t)b * cout * ys)) + (size_t)g * ys + yoff;
     wn_u4* yl = yh + (size_t)ng * ys;
     const int64_t n0 = (int64_t)S * q0 - pL;
     for (int i = threadIdx.x; i < S * DG_Q; i += 256) {
@@ -474,6 +494,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
     float* phase = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + wn_deconv_scratch_bytes(h, B, F)) -
                    dc_phase_floats(h, B, F);
     int L = F;
+    bool in_g4 = false;
     for (int j = 0; j < c.n_deconv; ++j) {
         const DeconvLayerPack& lp = sp.layers[j];
         const bool last = (j + 1 == c.n_deconv);
@@ -489,23 +510,26 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         }
         const int Q = L + 2;
         const int Qp = ((Q + DC_QW - 1) / DC_QW) * DC_QW;
+        // the fp16 GEMM of the NEXT layer reads G4 words when its input width allows it
+        const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);
         if (h_gemm) {
             dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
-            hipLaunchKernelGGL(deconv_mfma_h_kernel, g, dim3(256), 0, st, reinterpret_cast<const unsigned*>(x),
-                               lp.cin, xs, reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h), phase, lp.cout,
-                               Qp, lp.S, lp.taps, lp.inv_scale_h);
+            auto kern = in_g4 ? deconv_mfma_h_kernel<true> : deconv_mfma_h_kernel<false>;
+            hipLaunchKernelGGL(kern, g, dim3(256), 0, st, reinterpret_cast<const unsigned*>(x), lp.cin, xs,
+                               reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h), phase, lp.cout, Qp, lp.S,
+                               lp.taps, lp.inv_scale_h);
         } else {
             const int zc = (lp.cout + 255) / 256;
             dim3 g(Qp / DC_QT, lp.S, B * zc);
             hipLaunchKernelGGL(deconv_mfma_kernel, g, dim3(256), 0, st, x, lp.cin, xs, h->d_blob + lp.w_off, phase,
                                lp.cout, Qp, lp.S, lp.taps, zc);
         }
-        // intermediate outputs feed the next GEMM (split planes for the fp16 GEMM); the last one
-        // is split only when the caller consumes pair planes
-        if (last && split_out) {
+        // intermediate outputs feed the next GEMM; the last one is split (G4) only when the caller
+        // consumes the split layout
+        if ((last && split_out) || next_g4) {
             dim3 gi(Qp / DG_Q, lp.cout / 8, B);
             hipLaunchKernelGGL(deconv_interleave_g4_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
-                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, L, lp.S, lp.pL, c.upsample_act);
+                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
         } else if (!last && h_gemm) {
             dim3 gi(Qp / DC_QT, lp.cout / 2, B);
             hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
@@ -516,6 +540,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,
                                lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
         }
+        in_g4 = next_g4;
         x = y;
         xs = (int)ys;
         next = y + (size_t)B * lp.cout * ys;
