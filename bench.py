@@ -148,7 +148,7 @@ def main():
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
     fence()
@@ -226,7 +226,7 @@ def main():
             rec['cpu_baseline'] = cpu_baseline(hp_dict, F)
         print(json.dumps(rec), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

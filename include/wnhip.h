@@ -94,7 +94,8 @@ typedef struct wn_config {
     int32_t share_deconv;                   /* use_share_deconv || use_teacher_deconv */
     int32_t use_weight_norm;
     int32_t upsample_act;
-    int32_t reserved[8];
+    int32_t reserved[8];                    /* [0] = precision of the IAF / upsampler contractions:
+                                               0 split-fp16 x3 on the fp16 MFMA (default), 1 fp32 MFMA */
 } wn_config;
 
 typedef struct wn_handle wn_handle;
