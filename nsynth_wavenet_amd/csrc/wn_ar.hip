@@ -11,8 +11,14 @@
 // GEMV kernels that is captured once in a hipGraph (AR_GRAPH_STEPS steps per
 // graph) and replayed; no host round trip per sample.
 //
-// Round-1 form: weights are streamed from L2/Infinity-Cache every step by
-// wave-per-output-row GEMV kernels (latency bound).
+// Two step implementations, chosen by batch size:
+//  * B < 4: wave-per-output-row GEMV kernels, activations [batch][feature];
+//  * B >= 4: the batch is the N dimension of v_mfma_f32_16x16x4_f32 (activations
+//    [feature][padded batch]), so one pass over the 119 MB of weights serves every utterance.
+// Both are chains of ~62-92 dependent, latency-bound launches per step.
+#include <cstdlib>
+#include <cstring>
+
 #include "wn_internal.h"
 #include "wn_codec.h"
 
@@ -29,23 +35,39 @@ struct ArDims {
 
 // State blob (floats): [hdr 64][a_prev B][u ring 4*B][rings...][l B*W][s B*S][g B*G/2][z B*S][out B*OW][ebuf B*OW]
 struct ArStateLayout {
-    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, total;
+    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, encT, slab, total;
+    int NB;      // 0: GEMV layout [batch][feature]; >0: MFMA layout [feature][NB] (NB = padded batch)
 };
+
+// The batched (MFMA) step keeps activations feature-major / batch-minor so that the batch is
+// the N dimension of v_mfma_f32_16x16x4_f32: one pass over the weights serves every utterance.
+int ar_padded_batch(int B, bool has_b_pack = true) {
+    const char* mode = getenv("WN_AR_MODE");                  // "gemv" | "mfma" override (tests, A/B)
+    if (mode && !strcmp(mode, "gemv")) return 0;
+    if (B < 4 && !(mode && !strcmp(mode, "mfma"))) return 0;   // measured: the GEMV step wins below 4 utterances
+    if (!has_b_pack) return 0;
+    return B <= 16 ? 16 : B <= 32 ? 32 : (B + 63) / 64 * 64;
+}
 
 ArStateLayout ar_state_layout(const wn_handle* h, int B) {
     const wn_config& c = h->cfg;
     ArStateLayout L;
+    L.NB = ar_padded_batch(B, h->ar.wss_b_off != 0);
+    const size_t Bp = L.NB ? L.NB : B;
     size_t o = AR_HDR;
     auto carve = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };
     L.a_prev = carve(B);
     L.uring = carve(4 * (size_t)B);
-    L.rings = carve(h->ar.ring_floats * B);
-    L.l = carve((size_t)B * c.width);
-    L.s = carve((size_t)B * c.skip_width);
-    L.g = carve((size_t)B * c.gate_width / 2);
-    L.z = carve((size_t)B * c.skip_width);
-    L.out = carve((size_t)B * c.out_width);
+    L.rings = carve(h->ar.ring_floats * Bp);
+    L.l = carve(Bp * c.width);
+    L.s = carve(Bp * c.skip_width);
+    L.g = carve(Bp * c.gate_width / 2);
+    L.z = carve(Bp * c.skip_width);
+    L.out = carve(Bp * (size_t)((c.out_width + 15) / 16 * 16));
     L.ebuf = carve((size_t)B * c.out_width);
+    L.encT = carve(Bp * c.deconv_width);
+    // K-split partial pre-activations of the gate GEMM: [ceil(K/256)][gate_width][NB]
+    L.slab = carve(L.NB ? (size_t)((3 * c.width + c.deconv_width + 255) / 256) * c.gate_width * Bp : 0);
     L.total = o;
     return L;
 }
@@ -85,7 +107,8 @@ __global__ void ar_start_kernel(float* __restrict__ state, ArStateLayout L, ArDi
 // chunk EVERY load (weights, then the batch's inputs) is issued before the first use -- a
 // plain `for k` loop waits one L2/Infinity-Cache round trip per iteration, which at batch 1
 // was most of the step time.  Weights are held in registers across the batch loop.
-constexpr int AR_KC = 4;                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
+constexpr int AR_KC = 4;
+constexpr int AR_MAXSLAB = 8;       // K-split slabs of the batched gate GEMM (K <= 2048)                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
 
 // ---- generic row GEMV: y[b][o] (op)= bias[o] + W[o][:] . x[b][:]  (masked.py:383-405) ----
 // MODE 0: skip_start  s  = .            x = l
@@ -248,9 +271,12 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
-    const float* out = state + L.out + (size_t)b * D.OW;
+    // network output of batch element b: [b][o] (GEMV layout) or [o][NB] (MFMA layout)
+    const float* outb = state + L.out + (L.NB ? (size_t)b : (size_t)b * D.OW);
+    const int so = L.NB ? L.NB : 1;
+#define out(i) outb[(size_t)(i) * so]
     if (out_params)
-        for (int i = tid; i < D.OW; i += 256) out_params[((size_t)b * Tn + ti) * D.OW + i] = out[i];
+        for (int i = tid; i < D.OW; i += 256) out_params[((size_t)b * Tn + ti) * D.OW + i] = out(i);
 
     // randoms: injected [Tn][B][n_rand] or Philox(seed; step, batch, lane)
     auto rnd_at = [&](int j) -> float {
@@ -268,13 +294,13 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
     int q = 0;
     if (D.loss == WN_LOSS_MOL) {
         // loss_func.py:154-186
-        if (tid < D.M) sel_val[tid] = out[tid] - logf(-logf(rnd_at(tid)));
+        if (tid < D.M) sel_val[tid] = out(tid) - logf(-logf(rnd_at(tid)));
         __syncthreads();
         if (tid == 0) {
             int k = 0;
             for (int i = 1; i < D.M; ++i) if (sel_val[i] > sel_val[k]) k = i;   // first max, like argmax
-            const float mean = out[D.M + k];
-            const float ls = fminf(fmaxf(out[2 * D.M + k], -7.f), 7.f);
+            const float mean = out(D.M + k);
+            const float ls = fminf(fmaxf(out(2 * D.M + k), -7.f), 7.f);
             const float u2 = rnd_at(D.M);
             const float x = mean + expf(ls) * (logf(u2) - logf(1.f - u2));
             q = wn_clip_quantize(x, D.Q);
@@ -282,13 +308,13 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
     } else if (D.loss == WN_LOSS_GAUSS) {
         // loss_func.py:66-75,200-206
         if (tid == 0) {
-            const float x = out[0] + expf(fmaxf(out[1], -7.f)) * rnd_at(0);
+            const float x = out(0) + expf(fmaxf(out(1), -7.f)) * rnd_at(0);
             q = wn_clip_quantize(x, D.Q);
         }
     } else {
         // categorical draw by inverse CDF from one uniform (sequential fp32 running sum)
         float mx = -INFINITY;
-        for (int i = tid; i < D.OW; i += 256) mx = fmaxf(mx, out[i]);
+        for (int i = tid; i < D.OW; i += 256) mx = fmaxf(mx, out(i));
         red[tid] = mx;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
         }
         mx = red[0];
         float* e = state + L.ebuf + (size_t)b * D.OW;
-        for (int i = tid; i < D.OW; i += 256) e[i] = expf(out[i] - mx);
+        for (int i = tid; i < D.OW; i += 256) e[i] = expf(out(i) - mx);
         __syncthreads();
         if (tid == 0) {
             float tot = 0.f;
@@ -312,11 +338,195 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
             q = min(k, D.OW - 1) - D.Q / 2;                      // loss_func.py:149
         }
     }
+#undef out
     if (tid == 0) {
         const float a = wn_dequant(q, D.Q, D.mu);
         state[L.a_prev + b] = a;
         if (idx) idx[(size_t)b * Tn + ti] = q;
         if (wav) wav[(size_t)b * Tn + ti] = a;
+    }
+}
+
+// =====================  batched step: the batch is the MFMA N dimension  =====================
+// Weights are packed in A-fragment order ([row block][k-group of 16][lane][4], one coalesced
+// 16-byte load per lane = 4 K-steps of v_mfma_f32_16x16x4_f32); activations are [feature][NB].
+// One workgroup = one 16-row block x one chunk of 16*NT batch columns; its four waves split K
+// (the step is a chain of ~62 latency-bound launches: more, shorter waves) and meet in LDS.
+
+__global__ void ar_start_b_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
+                                  const float* __restrict__ wav_in, const float* __restrict__ forced,
+                                  const float* __restrict__ enc, int Tn, int per_step, const float* __restrict__ wb) {
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const int NB = L.NB;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = D.W > D.Cd ? D.W : D.Cd;
+    if (i >= rows * NB) return;
+    const int c = i / NB, b = i - c * NB;
+    float a = 0.f;
+    if (b < D.B) {
+        if (wav_in) a = wav_in[b];
+        else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
+        else a = t > 0 ? state[L.a_prev + b] : 0.f;
+    }
+    if (c < D.Cd) state[L.encT + (size_t)c * NB + b] = b < D.B ? enc[((size_t)b * Tn + ti) * D.Cd + c] : 0.f;
+    if (c < D.W) {
+        const float u = D.mu ? wn_mu_law_scaled(a) : a;
+        float u1 = 0.f, u2 = 0.f;
+        float* ur = state + L.uring;
+        if (b < D.B) {
+            u1 = ur[((t + 3) & 3) * D.B + b];
+            u2 = ur[((t + 2) & 3) * D.B + b];
+        }
+        state[L.l + (size_t)c * NB + b] = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+        if (c == 0 && b < D.B) ur[(t & 3) * D.B + b] = u;
+    }
+}
+
+// MODE 0 skip_start: s = W l            MODE 1 res/skip: l += W g (rows < W, + ring push), s += W g
+// MODE 2 out1: z = relu(W [relu(s)|enc]) MODE 3 out2: out = W z
+// MODE 4 gate pre-activations: K is split over blockIdx.z (256 inputs per workgroup, so that all
+//        256 CUs stream weights) and each workgroup writes its partial sums as a slab
+//        [kz][row][NB]; x = [ring[t-2d] | ring[t-d] | l | enc].  ar_gate_fin_b_kernel sums the
+//        slabs in a fixed order, adds the bias and applies sigmoid * tanh.
+// g[k][b] = sigmoid(bias[k] + sum_z slab[z][k][b]) * tanh(bias[m+k] + sum_z slab[z][m+k][b])  (wavenet.py:479)
+__global__ void ar_gate_fin_b_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
+                                     const float* __restrict__ bias, int nslab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = D.G / 2, NB = L.NB;
+    if (i >= m * NB) return;
+    const int k = i / NB, b = i - k * NB;
+    const float* slab = state + L.slab;
+    float vs[AR_MAXSLAB], vt[AR_MAXSLAB];
+#pragma unroll
+    for (int z = 0; z < AR_MAXSLAB; ++z)
+        if (z < nslab) {
+            vs[z] = slab[((size_t)z * D.G + k) * NB + b];
+            vt[z] = slab[((size_t)z * D.G + m + k) * NB + b];
+        }
+    float hs = bias[k], ht = bias[m + k];
+#pragma unroll
+    for (int z = 0; z < AR_MAXSLAB; ++z)
+        if (z < nslab) { hs += vs[z]; ht += vt[z]; }
+    state[L.g + (size_t)k * NB + b] = (1.f / (1.f + expf(-hs))) * tanhf(ht);
+}
+
+template <int NT>
+struct VecNT { float v[NT]; };
+template <int NT>
+__device__ inline VecNT<NT> load_nt(const float* p) {
+    VecNT<NT> r;
+    if (NT == 1) r.v[0] = p[0];
+    else if (NT == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.v[0] = t.x; r.v[1 % NT] = t.y;
+    } else {
+        const f4 t = *reinterpret_cast<const f4*>(p);
+#pragma unroll
+        for (int e = 0; e < NT; ++e) r.v[e] = t[e & 3];
+    }
+    return r;
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Ap,
+    const float* __restrict__ bias, int rows, int K, size_t ring_off, int dil) {
+    constexpr int NRB = 1;
+    extern __shared__ __attribute__((aligned(16))) f4 red[];      // [waves][NT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int NB = L.NB;
+    const int mb = blockIdx.x;
+    const int col0 = blockIdx.y * 16 * NT + NT * n;
+    const long long t = ar_step_of(state);
+    const int nks4 = K / 16;
+    // MODE 4: this workgroup owns k-groups [16*z, 16*z+16); otherwise all of K
+    const int g0 = MODE == 4 ? 16 * blockIdx.z : 0, g1 = MODE == 4 ? min(nks4, g0 + 16) : nks4;
+    const int per = (g1 - g0 + nw - 1) / nw;
+    const int k4a = g0 + wave * per, k4b = min(g1, k4a + per);
+    const int nslab = (3 * D.W + D.Cd + 255) / 256;
+
+    const float* ring = state + L.rings + ring_off * NB;
+    const size_t slot2 = (size_t)(t % (2 * dil)) * D.W, slot1 = (size_t)((t + dil) % (2 * dil)) * D.W;
+    // row pointer of input feature k (a k-group of 16 never straddles two sources)
+    auto xrow = [&](int k) -> const float* {
+        if (MODE == 0) return state + L.l + (size_t)k * NB;
+        if (MODE == 1) return state + L.g + (size_t)k * NB;
+        if (MODE == 2) return k < D.S ? state + L.s + (size_t)k * NB : state + L.encT + (size_t)(k - D.S) * NB;
+        if (MODE == 3) return state + L.z + (size_t)k * NB;
+        if (k < D.W) return ring + (slot2 + k) * NB;
+        if (k < 2 * D.W) return ring + (slot1 + (k - D.W)) * NB;
+        if (k < 3 * D.W) return state + L.l + (size_t)(k - 2 * D.W) * NB;
+        return state + L.encT + (size_t)(k - 3 * D.W) * NB;
+    };
+    f4 acc[NRB][NT];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int e = 0; e < NT; ++e) acc[rb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+    const f4* A0 = reinterpret_cast<const f4*>(Ap) + (size_t)mb * nks4 * 64 + lane;
+#pragma unroll 4
+    for (int k4 = k4a; k4 < k4b; ++k4) {
+        f4 a[NRB];
+        a[0] = A0[(size_t)k4 * 64];
+        float bv[4][NT];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k = 16 * k4 + 4 * jj + q;
+            const VecNT<NT> xv = load_nt<NT>(xrow(k) + col0);
+#pragma unroll
+            for (int e = 0; e < NT; ++e) bv[jj][e] = xv.v[e];
+            if (MODE == 2 && 16 * k4 < D.S) {
+#pragma unroll
+                for (int e = 0; e < NT; ++e) bv[jj][e] = fmaxf(bv[jj][e], 0.f);     // wavenet.py:494
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int e = 0; e < NT; ++e)
+                    acc[rb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][jj], bv[jj][e], acc[rb][e], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int e = 0; e < NT; ++e) red[((wave * NRB + rb) * NT + e) * 64 + lane] = acc[rb][e];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+        f4 v[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            v[rb] = red[(rb * NT + e) * 64 + lane];
+            for (int w = 1; w < nw; ++w) v[rb] += red[((w * NRB + rb) * NT + e) * 64 + lane];   // fixed order
+        }
+        const int col = col0 + e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mb + 4 * q + r;
+            if (MODE == 4) {
+                state[L.slab + ((size_t)blockIdx.z * D.G + row) * NB + col] = v[0][r];
+            } else if (row < rows) {
+                const float val = v[0][r] + bias[row];
+                if (MODE == 0) state[L.s + (size_t)row * NB + col] = val;
+                else if (MODE == 1) {
+                    if (row < D.W) {
+                        float* lp = state + L.l + (size_t)row * NB + col;
+                        const float lold = *lp;
+                        // push the layer INPUT into slot t mod 2d (masked.py:357-359)
+                        state[L.rings + ring_off * NB + ((size_t)(t % (2 * dil)) * D.W + row) * NB + col] = lold;
+                        *lp = lold + val;
+                    } else {
+                        state[L.s + (size_t)(row - D.W) * NB + col] += val;
+                    }
+                } else if (MODE == 2) state[L.z + (size_t)row * NB + col] = fmaxf(val, 0.f);   // wavenet.py:499
+                else state[L.out + (size_t)row * NB + col] = val;
+            }
+        }
     }
 }
 
@@ -334,11 +544,54 @@ ArDims ar_dims(const wn_handle* h, int B) {
 }
 
 // enqueue the kernels of ONE step (wavenet.py:408-501 + sampler + queue pushes)
+template <int NT>
+void ar_enqueue_step_b(wn_handle* h, float* state, const ArStateLayout& L, const ArDims& D, const float* wav_in,
+                       const float* forced, const float* enc, int Tn, int per_step, const float* rnd,
+                       uint64_t seed, int* idx, float* wav, float* out_params, hipStream_t st) {
+    const ArPack& P = h->ar;
+    const float* blob = h->d_blob;
+    const int NB = L.NB, chunks = NB / (16 * NT);
+    const int rows = D.W > D.Cd ? D.W : D.Cd;
+    // waves per workgroup = K-split: as many as there are k-groups / 4, capped by 16 waves and
+    // by 64 KB of LDS for the partial accumulators
+    auto nwaves = [&](int K, int nrb) {
+        int w = K / 64;
+        const int cap = 65536 / (nrb * NT * 1024);
+        w = w > 16 ? 16 : w;
+        return w > cap ? cap : (w < 1 ? 1 : w);
+    };
+    auto lds = [&](int w, int nrb) { return (size_t)w * nrb * NT * 1024; };
+    const int w1 = nwaves(D.G / 2, 1), w0 = nwaves(D.W, 1), w2 = nwaves(D.S + D.Cd, 1), w3 = nwaves(D.S, 1);
+    const int nslab = (3 * D.W + D.Cd + 255) / 256;
+    hipLaunchKernelGGL(ar_start_b_kernel, dim3((rows * NB + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
+                       forced, enc, Tn, per_step, blob + P.start_off);
+    hipLaunchKernelGGL((ar_gemm_b_kernel<0, NT>), dim3(D.S / 16, chunks), dim3(64 * w0), lds(w0, 1), st, state, L, D,
+                       blob + P.wss_b_off, blob + P.bss_off, D.S, D.W, (size_t)0, 1);
+    for (const ArLayerPack& lp : P.layers) {
+        hipLaunchKernelGGL((ar_gemm_b_kernel<4, NT>), dim3(D.G / 16, chunks, nslab), dim3(256), lds(4, 1), st, state, L, D,
+                           blob + lp.wd_b_off, blob + lp.bd_off, D.G, 3 * D.W + D.Cd, lp.ring_off, lp.dilation);
+        hipLaunchKernelGGL(ar_gate_fin_b_kernel, dim3((D.G / 2 * NB + 255) / 256), dim3(256), 0, st, state, L, D,
+                           blob + lp.bd_off, nslab);
+        hipLaunchKernelGGL((ar_gemm_b_kernel<1, NT>), dim3((D.W + D.S) / 16, chunks), dim3(64 * w1), lds(w1, 1), st, state, L, D,
+                           blob + lp.wrs_b_off, blob + lp.brs_off, D.W + D.S, D.G / 2, lp.ring_off, lp.dilation);
+    }
+    hipLaunchKernelGGL((ar_gemm_b_kernel<2, NT>), dim3(D.S / 16, chunks), dim3(64 * w2), lds(w2, 1), st, state, L, D,
+                       blob + P.wo1_b_off, blob + P.bo1_off, D.S, D.S + D.Cd, (size_t)0, 1);
+    hipLaunchKernelGGL((ar_gemm_b_kernel<3, NT>), dim3((D.OW + 15) / 16, chunks), dim3(64 * w3), lds(w3, 1), st, state, L, D,
+                       blob + P.wo2_b_off, blob + P.bo2_off, D.OW, D.S, (size_t)0, 1);
+    hipLaunchKernelGGL(ar_sample_kernel, dim3(D.B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
+                       per_step, Tn, idx, wav, out_params);
+    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
+}
+
 void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, const float* forced,
                      const float* enc, int Tn, int per_step, const float* rnd, uint64_t seed, int* idx,
                      float* wav, float* out_params, hipStream_t st) {
     const ArStateLayout L = ar_state_layout(h, B);
     const ArDims D = ar_dims(h, B);
+    if (L.NB == 16) return ar_enqueue_step_b<1>(h, state, L, D, wav_in, forced, enc, Tn, per_step, rnd, seed, idx, wav, out_params, st);
+    if (L.NB == 32) return ar_enqueue_step_b<2>(h, state, L, D, wav_in, forced, enc, Tn, per_step, rnd, seed, idx, wav, out_params, st);
+    if (L.NB) return ar_enqueue_step_b<4>(h, state, L, D, wav_in, forced, enc, Tn, per_step, rnd, seed, idx, wav, out_params, st);
     const ArPack& P = h->ar;
     const float* blob = h->d_blob;
     hipLaunchKernelGGL(ar_start_kernel, dim3((B * D.W + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
@@ -385,6 +638,8 @@ void wn_ar_release(wn_handle* h) {
 }
 
 // ---------------------------------------------------------------------------
+static bool K_ok(int k) { return k % 64 == 0; }   // every K of the batched GEMMs is a multiple of 64 (4 waves x 16)
+
 int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
     const wn_config& c = h->cfg;
     const int W = c.width, S = c.skip_width, G = c.gate_width, Cd = c.deconv_width, OW = c.out_width;
@@ -465,6 +720,38 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
         P.bo2_off = begin();
         const auto& b3 = var("out2/biases");
         blob.insert(blob.end(), b3.begin(), b3.end());
+        blob.resize(align_up(blob.size(), 64) + 64);      // slack: bias reads of padded rows stay in bounds
+    }
+    // A-fragment-order copies for the batched (MFMA) step: [row block][k-group of 16][lane][4],
+    // lane (i = lane&15, kq = lane>>4), element jj <-> W[16*mb + i][16*k4 + 4*jj + kq]
+    auto frag = [&](size_t src_off, int rows, int K) -> size_t {
+        const int mbs = (rows + 15) / 16, nks4 = K / 16;
+        const size_t off = begin();
+        blob.resize(blob.size() + (size_t)mbs * nks4 * 256);
+        const float* src = blob.data() + src_off;
+        float* dst = blob.data() + off;
+        for (int mb = 0; mb < mbs; ++mb)
+            for (int k4 = 0; k4 < nks4; ++k4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int row = 16 * mb + (lane & 15), k = 16 * k4 + 4 * jj + (lane >> 4);
+                        dst[(((size_t)mb * nks4 + k4) * 64 + lane) * 4 + jj] = row < rows ? src[(size_t)row * K + k] : 0.f;
+                    }
+        return off;
+    };
+    P.wss_b_off = 0;
+    if (K_ok(W) && K_ok(Cd) && K_ok(S) && K_ok(G / 2) && (3 * W + Cd + 255) / 256 <= AR_MAXSLAB) {
+        P.wss_b_off = frag(P.wss_off, S, W);
+        for (ArLayerPack& lp : P.layers) {
+            lp.wd_b_off = frag(lp.wd_off, G, 3 * W + Cd);
+            lp.wrs_b_off = frag(lp.wrs_off, W + S, G / 2);
+            // bias vector of the batched res/skip kernel: [res | skip | gate (dilated + cond)]
+            lp.brs_gate_off = begin();
+            for (int i = 0; i < W + S; ++i) blob.push_back(blob[lp.brs_off + i]);
+            for (int i = 0; i < G; ++i) blob.push_back(blob[lp.bd_off + i]);
+        }
+        P.wo1_b_off = frag(P.wo1_off, S, S + Cd);
+        P.wo2_b_off = frag(P.wo2_off, OW, S);
     }
     return WN_OK;
 }

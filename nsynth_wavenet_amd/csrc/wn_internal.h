@@ -57,6 +57,8 @@ struct ArLayerPack {
     size_t bd_off;    // [gate]  (dilated bias + cond bias)
     size_t wrs_off;   // [width + skip][gate/2]            (res rows then skip rows)
     size_t brs_off;   // [width + skip]
+    size_t wd_b_off, wrs_b_off;   // the same matrices in MFMA A-fragment order (batched step)
+    size_t brs_gate_off;          // [res | skip | gate] biases for the batched res/skip kernel
     int dilation;
     size_t ring_off;  // float offset of this layer's ring inside the state (per batch elem)
 };
@@ -66,6 +68,7 @@ struct ArPack {
     std::vector<ArLayerPack> layers;
     size_t wo1_off, bo1_off;   // [skip][skip + deconv_width], [skip] (out1 | mel_cond_out1)
     size_t wo2_off, bo2_off;   // [out_width][skip], [out_width]
+    size_t wss_b_off, wo1_b_off, wo2_b_off;   // A-fragment order copies
     size_t ring_floats;        // per batch element
 };
 

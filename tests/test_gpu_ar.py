@@ -119,3 +119,36 @@ def test_fastgen_mirror_and_cli(tmp_path):
     s = fg.sample({'wav': np.random.uniform(-1, 1, [4, 1]), 'encoding': np.random.uniform(-1, 1, [4, 256])},
                   rnd=np.zeros([4, 1], np.float32))
     assert s['sample'].shape == (4, 1) and str(s['sample'].dtype) == 'torch.int32'
+
+
+@pytest.mark.parametrize('B', [5, 20, 40])
+def test_batched_mfma_step_matches_gemv_step_and_oracle(B, monkeypatch):
+    """B >= 4 runs the batched step (batch = MFMA N dimension, K-split slabs); it must agree
+    with the GEMV step (forced through WN_AR_MODE) and with the full-sequence teacher (K1)."""
+    import torch
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, 'ar_mol.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
+    rs = np.random.RandomState(B)
+    Tn = 24
+    enc = (rs.standard_normal([B, Tn, hp.deconv_width]) * 0.5).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    rnd = rs.uniform(1e-5, 1 - 1e-5, [Tn, B, 11]).astype(np.float32)
+    ref = O.teacher_feed_forward(O.encode_signal(forced, hp, np.float64), np.pad(enc, ((0, 0), (0, 0), (0, 0))).astype(np.float64),
+                                 w, hp, np.float64) if Tn % 4 == 0 else None
+    outs = {}
+    for mode in ('mfma', 'gemv'):
+        monkeypatch.setenv('WN_AR_MODE', mode)
+        eng = Engine(cfgd).load_weights(w)
+        a = eng.ar_generate(enc, rnd, forced_wav=forced, want_out=True)
+        b = eng.ar_generate(enc, rnd, want_out=True)
+        outs[mode] = (_np(a['out_params']), _np(b['idx']), _np(b['out_params']))
+        eng.close()
+    assert np.abs(outs['mfma'][0] - outs['gemv'][0]).max() <= 2e-5 * max(1.0, np.abs(outs['gemv'][0]).max())
+    if ref is not None:
+        assert np.abs(outs['mfma'][0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    agree = (outs['mfma'][1] == outs['gemv'][1]).mean()
+    assert agree > 0.9                       # free-running streams fork only where float noise crosses floor()
