@@ -33,6 +33,7 @@ from nsynth_wavenet_amd.engine import Engine             # noqa: E402
 # per generated sample (BASELINE.md section 2 / SURVEY section 8d)
 LAYER_FLOP_PER_SAMPLE = 61440          # one residual layer: 2 * (12288 + 16384 + 2048) MAC
 LAYER_BYTES_PER_SAMPLE = 1536          # read l 256 B + read mel_en 1024 B + write l 256 B
+LAYER_BYTES_PER_SAMPLE_HOISTED = 768   # read l 256 B + read hoisted cond term 256 B + write l 256 B
 PATH_FLOP_PER_SAMPLE = 4385280
 PATH_BYTES_PER_SAMPLE = 98484
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
@@ -111,7 +112,7 @@ def main():
     ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=None, choices=['f16x3', 'f32'],
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     args = ap.parse_args()
 
@@ -173,7 +174,19 @@ def main():
         bytes_per_launch = LAYER_BYTES_PER_SAMPLE * B * T
         achieved_tf = flops_per_launch / avg_layer_s / 1e12
         achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
-        if eng.precision == 'f16x3':
+        hoisted = eng.iaf_cond_hoisted(B, F)
+        if hoisted:
+            # conditioning 1x1s hoisted into one GEMM per deconv stack (large batches): the layer
+            # kernel streams l in/out and the projected term, 768 B/sample
+            bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
+            achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+            roof = {'kernel': 'iaf_layer_c_kernel (dilated conv + gate + residual 1x1 on hoisted conditioning, split-fp16 MFMA)',
+                    'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                    'frac': achieved_gbps / PEAK_HBM_GBPS,
+                    'note': '768 B/sample/layer in this kernel + 256 B/sample/layer written by iaf_cond_h_kernel '
+                            '(vs 1536 B/sample/layer of the fused layer kernel)'}
+            dtype = 'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
+        elif eng.precision.startswith('f16x3'):
             # split-fp16 operands on the fp16 MFMA: 3 MFMAs per product -> the matrix pipe needs
             # 3*61440 fp16-FLOP/sample at a 2.5 PFLOP/s peak (0.07 ns) vs 1536 B/sample at 8 TB/s
             # (0.19 ns): the kernel is HBM-bound
@@ -189,7 +202,7 @@ def main():
                     'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                     'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
             dtype = 'f32'
-        roof.update({'traffic': pmc_traffic(B, F, eng.precision),
+        roof.update({'traffic': None if hoisted else pmc_traffic(B, F, eng.precision),
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
                      'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
                      'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})

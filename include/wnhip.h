@@ -95,7 +95,10 @@ typedef struct wn_config {
     int32_t use_weight_norm;
     int32_t upsample_act;
     int32_t reserved[8];                    /* [0] = precision of the IAF / upsampler contractions:
-                                               0 split-fp16 x3 on the fp16 MFMA (default), 1 fp32 MFMA */
+                                               0 split-fp16 x3 on the fp16 MFMA (default), 1 fp32 MFMA
+                                               [1] = where the split-fp16 path evaluates the per-layer
+                                               conditioning 1x1s: 0 chosen per call from batch x length,
+                                               1 inside every layer kernel, 2 one GEMM per deconv stack */
 } wn_config;
 
 typedef struct wn_handle wn_handle;
@@ -205,6 +208,10 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
  * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
  * summed elapsed milliseconds and the number of layer-kernel launches they
  * bracket, so that average launch duration = layer_ms / layer_launches. */
+/* 1 when wn_iaf_generate(B, F) evaluates the per-layer conditioning 1x1s in one hoisted GEMM per
+ * deconv stack (the layer kernels then stream 768 B/sample instead of 1536), else 0. */
+int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
+
 int wn_profile_begin(wn_handle* h);
 int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches);
 

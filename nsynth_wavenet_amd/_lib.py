@@ -17,7 +17,7 @@ ERRNAMES = {-22: 'WN_EINVAL', -2: 'WN_ENOENT', -12: 'WN_ENOMEM', -5: 'WN_EIO', -
 SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_iaf_length',
            'wn_ar_length', 'wn_workspace_bytes', 'wn_deconv', 'wn_iaf_generate', 'wn_clip_quant',
            'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate',
-           'wn_profile_begin', 'wn_profile_end', 'wn_last_error', 'wn_destroy']
+           'wn_iaf_cond_hoisted', 'wn_profile_begin', 'wn_profile_end', 'wn_last_error', 'wn_destroy']
 
 
 class WnConfig(ctypes.Structure):

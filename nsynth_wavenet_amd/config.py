@@ -56,12 +56,16 @@ def iaf_length(hparams, num_frames):
     return (num_frames * frame_shift(hparams) // md) * md
 
 
-PRECISIONS = {'f16x3': 0, 'f32': 1}
+# name -> (wn_config.reserved[0] arithmetic, reserved[1] conditioning placement)
+PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}
 
 
 def default_precision():
     """IAF contraction arithmetic: 'f16x3' = split-fp16 operands on the fp16 MFMA (three MFMAs per
-    product, ~22-bit operands, fp32 accumulate) -- the default; 'f32' = fp32 MFMA."""
+    product, ~22-bit operands, fp32 accumulate) -- the default; it evaluates the per-layer
+    conditioning 1x1s inside every layer kernel for small batches and hoists them into one GEMM
+    per deconv stack once batch x length outgrows the Infinity Cache ('f16x3-fused' /
+    'f16x3-hoisted' force either form); 'f32' = fp32 MFMA."""
     import os
     return os.environ.get('WN_PRECISION', 'f16x3')
 
@@ -72,7 +76,7 @@ def to_wn_config(hparams, kind=None, n_mel=80, precision=None):
     precision = precision or default_precision()
     if precision not in PRECISIONS:
         raise ValueError('precision must be one of {}'.format(sorted(PRECISIONS)))
-    c.reserved[0] = PRECISIONS[precision]
+    c.reserved[0], c.reserved[1] = PRECISIONS[precision]
     if getattr(hparams, 'use_resize_conv', False):
         raise ValueError('use_resize_conv=true is not supported (disabled in every shipped config)')
     dc = hparams.deconv_config

@@ -82,7 +82,12 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
     if (c.reserved[0] != WN_PREC_F16X3 && c.reserved[0] != WN_PREC_F32)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.reserved[0]);
+    if (c.reserved[1] < WN_COND_AUTO || c.reserved[1] > WN_COND_HOISTED)
+        return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.reserved[1]);
     if (c.kind == WN_KIND_STUDENT) {
+        if (c.num_stages < 7)
+            return wn_fail(nullptr, WN_EINVAL, "config: the IAF kernels tile time in 64-sample blocks and need "
+                           "num_stages >= 7 (output length is a multiple of 2^(num_stages-1)), got %d", c.num_stages);
         if (c.width != IAF_W || c.gate_width != IAF_W || c.deconv_width != IAF_CD)
             return wn_fail(nullptr, WN_EINVAL,
                            "config: the IAF kernels are specialised for width 64 / deconv_width 256 "

@@ -1,0 +1,533 @@
+// Split-fp16 IAF path with the conditioning GEMMs hoisted out of the residual layers.
+//
+// Every residual layer and every flow head adds a 1x1 projection of the SAME upsampled
+// conditioning `enc` (256 channels) to its pre-activation (parallel_wavenet.py:240-244,
+// :258-262); the reference itself evaluates those projections in bulk for the AR path
+// (`Fastgen.cond_vars`, wavenet.py:353-377).  Reading `enc` in every layer costs
+// 1024 B/sample/layer of the 1536 the fused layer kernel (wn_iaf_h.hip) moves.  Here one GEMM
+// per deconv stack (iaf_cond_h_kernel) reads `enc` ONCE and writes, for every layer and head
+// ("row block" = 64 output channels), the projected term C in the MFMA accumulator layout;
+// the layer kernel then streams l (256 B read + 256 B write) and C (256 B read) per sample:
+// 768 + 256 (C write) = 1024 B/sample/layer instead of 1536, and its weight image shrinks to
+// 57 KB of LDS so two workgroups share a CU.
+//
+// C layout: [batch][row block][column block cb = t/16][mb = 16-row block][lane][4 floats] --
+// exactly the D registers of v_mfma_f32_16x16x32_f16 (row 16mb + 4(lane>>4) + r, column
+// 16cb + (lane&15)), so both sides move it with one 16-byte access per lane, 1 KB per wave.
+// Values are the raw fp32 accumulators of the pre-scaled weights (same scale as the layer's
+// dilated-conv fragments), so they are the C-in of the layer's first MFMA.
+#include <algorithm>
+#include <cstdlib>
+
+#include "wn_internal.h"
+#include "wn_codec.h"
+#include "wn_mfma_h.h"
+
+namespace {
+
+constexpr int CK_NC = 128;                       // columns of one conditioning-GEMM task
+constexpr int CK_THREADS = 512;                  // 8 waves: two per SIMD hide each other's load / store latency
+constexpr int CK_LDS_BYTES = 2 * 32 * CK_NC * 16;   // enc tile: [plane][group][column] x 16 B
+constexpr int LC_A_WORDS = 6 * 4 * 2 * 256;      // dilated-conv fragments (K-steps 0-5)
+constexpr int LC_TAIL_WORDS = IAF_PR_FLOATS + 128 + 4;
+constexpr int LC_LDS_WORDS = LC_A_WORDS + LC_TAIL_WORDS;
+constexpr int HC_A_WORDS = 2 * 4 * 2 * 256;      // out1 fragments (K-steps 0-1)
+constexpr int HC_TAIL_WORDS = 64 * 3 + 4;
+constexpr int HC_LDS_WORDS = HC_A_WORDS + HC_TAIL_WORDS;
+
+// ---------------- conditioning GEMM: C[rb] = Wcond[rb] (64 x 256) . enc (256 x T) ----------------
+// One task = (batch row, 128-column tile, chunk of row blocks).  The enc tile is staged once in
+// LDS as ready-made B operands; each wave then owns whole row blocks: its A fragments come
+// straight from L2 in fragment order (1 KB per wave load), every fragment is used against
+// the 8 column blocks of the tile, every B operand read from LDS feeds 12 MFMAs.
+__global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
+    const unsigned* __restrict__ enc, const unsigned* __restrict__ wblob, const unsigned* __restrict__ rb_off,
+    float* __restrict__ C, int64_t c_bstride, int64_t TE, int c0, int R, int CH, int nchunks, int tiles_per_row,
+    int ntiles, int64_t NCB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    constexpr int NW = CK_THREADS / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    wn_u4* Bt = reinterpret_cast<wn_u4*>(ldsw);
+    const int TE16 = (int)TE * 16;
+
+    int first, end, step, t_lo;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, per = (ntiles + 7) >> 3;
+        t_lo = xcd * per;
+        const int t_hi = min(ntiles, t_lo + per);
+        first = blockIdx.x >> 3;
+        step = gridDim.x >> 3;
+        end = t_hi > t_lo ? (t_hi - t_lo) * nchunks : 0;
+    } else {
+        t_lo = 0;
+        first = blockIdx.x;
+        step = gridDim.x;
+        end = ntiles * nchunks;
+    }
+    for (int task = first; task < end; task += step) {
+        const int tile = t_lo + task / nchunks, chunk = task % nchunks;
+        const int b = tile / tiles_per_row;
+        const int j = tile - b * tiles_per_row;
+        const int rb_end = min(R, (chunk + 1) * CH);
+        int rb = chunk * CH + wave;
+        // first A fragments of this wave's first row block: in flight while the tile is staged
+        wn_u4 a[2][4][2];
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7ffffff0, 0x00020000);
+        {
+            const int ao = (int)rb_off[min(rb, R - 1)] * 4;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                a[0][mb][0] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 0) * 1024);
+                a[0][mb][1] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 1) * 1024);
+            }
+        }
+        // ---- stage the enc tile: 64 rows (plane, group) x 128 columns x 16 B ----
+        {
+            const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(enc + (size_t)b * IAF_CD * TE), 0, IAF_CD * (int)TE * 4, 0x00020000);
+            constexpr int RP = CK_THREADS / CK_NC;          // rows per pass
+            const int col = threadIdx.x & (CK_NC - 1), rp = threadIdx.x / CK_NC;
+            const int vo = (c0 + CK_NC * j + col) * 16 + rp * TE16;
+            __syncthreads();                      // previous task's operand reads are done
+#pragma unroll
+            for (int c4 = 0; c4 < 64 / RP / 4; ++c4) {
+                wn_u4 tmp[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) tmp[p] = buf_ld4(re, vo, (RP * (4 * c4 + p)) * TE16);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_NC + col] = tmp[p];
+            }
+            __syncthreads();
+        }
+        for (; rb < rb_end; rb += NW) {
+            const int ao = (int)rb_off[rb] * 4, an = (int)rb_off[min(rb + NW, R - 1)] * 4;
+            const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(C + (size_t)b * c_bstride + ((size_t)rb * NCB) * 1024), 0, (int)NCB * 4096, 0x00020000);
+            f4 acc[4][8];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = (f4){0.f, 0.f, 0.f, 0.f};
+            // B operands one (K-step, column block) ahead of the MFMAs that use them
+            wn_u4 bb[2][2];
+            bb[0][0] = Bt[q * CK_NC + n];
+            bb[0][1] = Bt[(32 + q) * CK_NC + n];
+            auto store_nb = [&](int nb) {
+                // column blocks past the end of the row fall outside the descriptor and are dropped
+                const int cb = (CK_NC / 16) * j + nb;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    buf_st4(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16, (cb * 4 + mb) * 1024);
+            };
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                // next K-step's fragments (the next row block's first ones at the end)
+                const int an1 = ks + 1 < 8 ? ao + (ks + 1) * 8 * 1024 : an;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
+                    a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) {
+                    const int cur = nb & 1;
+                    if (ks * 8 + nb + 1 < 64) {
+                        const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
+                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
+                    // results of a column block leave while the next one is being computed
+                    if (ks == 7 && nb >= 1) store_nb(nb - 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_nb(7);
+        }
+    }
+}
+
+struct CSrc {
+    __amdgpu_buffer_rsrc_t rl, rc;
+    int vo[3];
+    int vc;
+};
+
+__device__ inline f4 buf_ldf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// ---------------- residual layer with hoisted conditioning ----------------
+// Same contraction as iaf_layer_h_kernel minus its eight enc K-steps: the accumulators start
+// from the C tile.  Column map of a wave: 16 HN columns, column block e = columns 16e..16e+15.
+template <int HN>
+__global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
+    const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
+    const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    constexpr int TILE = 64 * HN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
+    const wn_u4* PRl = Pl + 6 * 4 * 2 * 64;
+    const float* ldsf = reinterpret_cast<const float*>(ldsw);
+    const float* bg = ldsf + LC_A_WORDS + IAF_PR_FLOATS + q * 16;
+    const float* br = bg + 64;
+    const int RS16 = (int)RS * 16;
+    const int lane_l = q * RS16 + (wave * 16 * HN + n + IAF_LP) * 16;
+    const int lane_c = wave * HN * 4096 + lane * 16;
+
+    auto tile_src = [&](int tile) -> CSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * TILE;
+        CSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        s.rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (size_t)b * c_bstride), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = lane_l + (tt - 2 * d) * 16;
+        s.vo[1] = lane_l + (tt - d) * 16;
+        s.vo[2] = lane_l + tt * 16;
+        s.vc = lane_c + tt * 256;
+        return s;
+    };
+    // K-steps 0-5: taps t-2d, t-d, t (two 32-channel steps each)
+    auto loadK = [&](const CSrc& s, int ks) -> KOp<HN> {
+        KOp<HN> o;
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            o.h[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 256 * e, (4 * (ks & 1)) * RS16);
+            o.l[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 256 * e, (8 + 4 * (ks & 1)) * RS16);
+        }
+        return o;
+    };
+
+    // Operand double buffer: ALL loads of tile k+1 are issued before tile k is computed, so a
+    // workgroup keeps one full tile (48 KB) in flight for the whole tile period.
+    auto load_tile = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN]) {
+        const CSrc s = tile_src(tile);
+#pragma unroll
+        for (int e = 0; e < HN; ++e)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) cp[mb][e] = buf_ldf4(s.rc, s.vc + (e * 4 + mb) * 1024, 0);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) bc[ks] = loadK(s, ks);
+    };
+    const TileWalk tw = tile_walk(ntiles);
+    const int tstep = tw.step, tend = tw.end;
+    float inv_m = 0.f, inv_r = 0.f;
+
+    auto body = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN], KOp<HN> (&bn)[6], f4 (&cn)[4][HN]) {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * TILE;
+        if (tile + tstep < tend) load_tile(tile + tstep, bn, cn);
+        f4 acc[4][HN];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < HN; ++e) acc[mb][e] = cp[mb][e];
+        wn_u4 a[2][4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            a[0][mb][0] = Pl[((0 * 4 + mb) * 2 + 0) * 64];
+            a[0][mb][1] = Pl[((0 * 4 + mb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            if (ks + 1 < 6) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = Pl[(((ks + 1) * 4 + mb) * 2 + 0) * 64];
+                    a[(ks + 1) & 1][mb][1] = Pl[(((ks + 1) * 4 + mb) * 2 + 1) * 64];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < HN; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue per column block: gate, residual 1x1, split, store
+        const __amdgpu_buffer_rsrc_t ro =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        const int vo_out = lane_l + tt * 16;
+        wn_u4 ar[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            ar[mb][0] = PRl[(mb * 2 + 0) * 64];
+            ar[mb][1] = PRl[(mb * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
+            float g[2][4];
+#pragma unroll
+            for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
+                               tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
+            wn_u4 gh, gl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned hw, lw;
+                wn_split_pair(g[i >> 1][(i & 1) * 2], g[i >> 1][(i & 1) * 2 + 1], hw, lw);
+                gh[i] = hw;
+                gl[i] = lw;
+            }
+            wn_u4 oh[2], ol[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f4 rc = mfma3(ar[mb][0], ar[mb][1], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    // l_old of channels 16mb+4q+2rp(+1): tap-t K-step 4+(mb>>1), slot 2(mb&1)+rp
+                    float l0, l1;
+                    wn_join_pair(bc[4 + (mb >> 1)].h[e][(mb & 1) * 2 + rp], bc[4 + (mb >> 1)].l[e][(mb & 1) * 2 + rp], l0, l1);
+                    const float v0 = l0 + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
+                    const float v1 = l1 + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
+                    unsigned hw, lw;
+                    wn_split_pair(v0, v1, hw, lw);
+                    oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
+                    ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                buf_st4(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
+                buf_st4(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
+            }
+        }
+    };
+
+    KOp<HN> bA[6], bB[6];
+    f4 cA[4][HN], cB[4][HN];
+    int tile = tw.first;
+    if (tile < tend) load_tile(tile, bA, cA);
+    // the weight image is staged AFTER the first tile's operand loads are in flight
+    stage_words<LC_A_WORDS>(wpack, ldsw);
+    stage_words<LC_TAIL_WORDS>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
+    inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
+    inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
+    while (tile < tend) {
+        body(tile, bA, cA, bB, cB);
+        tile += tstep;
+        if (tile >= tend) break;
+        body(tile, bB, cB, bA, cA);
+        tile += tstep;
+    }
+}
+
+// ---------------- flow head with hoisted conditioning (parallel_wavenet.py:256-277, :319-324) ----------------
+template <int HN>
+__global__ __launch_bounds__(256, 2) void iaf_head_c_kernel(
+    const unsigned* __restrict__ lin, const float* __restrict__ C, int64_t c_bstride, const unsigned* __restrict__ wpack,
+    float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
+    int64_t RS, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    constexpr int TILE = 64 * HN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;
+    const float* ldsf = reinterpret_cast<const float*>(ldsw);
+    const float* bo = ldsf + HC_A_WORDS + q * 16;
+    const float* wm = bo + 64;
+    const float* wsc = wm + 64;
+    const int RS16 = (int)RS * 16;
+    const int lane_l = q * RS16 + (wave * 16 * HN + n + IAF_LP) * 16;
+    const int lane_c = wave * HN * 4096 + lane * 16;
+
+    auto tile_src = [&](int tile) -> CSrc {
+        const int b = tile / tiles_per_row;
+        const int tt = (tile - b * tiles_per_row) * TILE;
+        CSrc s;
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        s.rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (size_t)b * c_bstride), 0, 0x7ffffff0, 0x00020000);
+        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 16;
+        s.vc = lane_c + tt * 256;
+        return s;
+    };
+    // K-steps 0-1: out1 over relu(l)
+    auto loadK = [&](const CSrc& s, int ks) -> KOp<HN> {
+        KOp<HN> o;
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            o.h[e] = buf_ld4(s.rl, s.vo[2] + 256 * e, (4 * ks) * RS16);
+            o.l[e] = buf_ld4(s.rl, s.vo[2] + 256 * e, (8 + 4 * ks) * RS16);
+        }
+        return o;
+    };
+    KOp<HN> bc[2];
+    f4 cpre[4][HN];
+    const TileWalk tw = tile_walk(ntiles);
+    const int tile0 = tw.first, tstep = tw.step, tend = tw.end;
+    if (tile0 < tend) {
+        const CSrc s0 = tile_src(tile0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bc[ks] = loadK(s0, ks);
+#pragma unroll
+        for (int e = 0; e < HN; ++e)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) cpre[mb][e] = buf_ldf4(s0.rc, s0.vc + (e * 4 + mb) * 1024, 0);
+    }
+    stage_words<HC_A_WORDS>(wpack, ldsw);
+    stage_words<HC_TAIL_WORDS>(wpack + IAF_PH_FLOATS, ldsw + HC_A_WORDS);
+    const float bmean = ldsf[HC_A_WORDS + 192], bscale = ldsf[HC_A_WORDS + 193];
+    const float inv_m = ldsf[HC_A_WORDS + 194];
+    for (int tile = tile0; tile < tend; tile += tstep) {
+        const int b = tile / tiles_per_row;
+        const int t0 = (tile - b * tiles_per_row) * TILE + wave * 16 * HN;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
+        const CSrc sn = tile_src(has_next ? next : tile);
+        f4 acc[4][HN];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < HN; ++e) acc[mb][e] = cpre[mb][e];
+        if (has_next) {
+#pragma unroll
+            for (int e = 0; e < HN; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) cpre[mb][e] = buf_ldf4(sn.rc, sn.vc + (e * 4 + mb) * 1024, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            wn_u4 a[4][2];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                a[mb][0] = Pl[((ks * 4 + mb) * 2 + 0) * 64];
+                a[mb][1] = Pl[((ks * 4 + mb) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int e = 0; e < HN; ++e) {
+                wn_u4 bh = bc[ks].h[e], bl = bc[ks].l[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {             // relu(l) (:256) on the reconstructed value
+                    float v0, v1;
+                    wn_join_pair(bh[i], bl[i], v0, v1);
+                    unsigned hw, lw;
+                    wn_split_pair(fmaxf(v0, 0.f), fmaxf(v1, 0.f), hw, lw);
+                    bh[i] = hw;
+                    bl[i] = lw;
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb][e] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[mb][e]);
+            }
+            if (has_next) bc[ks] = loadK(sn, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < HN; ++e) {
+            float pm = 0.f, ps = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = fmaxf(fmaf(acc[mb][e][r], inv_m, bo[mb * 4 + r]), 0.f);
+                    pm = fmaf(wm[mb * 4 + r], o, pm);
+                    ps = fmaf(wsc[mb * 4 + r], o, ps);
+                }
+            pm += __shfl_xor(pm, 16);
+            ps += __shfl_xor(ps, 16);
+            pm += __shfl_xor(pm, 32);
+            ps += __shfl_xor(ps, 32);
+            if (q == 0) {
+                const int64_t t = t0 + 16 * e + n;
+                const float mean = pm + bmean;
+                const float s = fminf(fmaxf(softplus_tf(ps + bscale), EXP_M9), EXP_7);   // :105-114
+                float* xp = x + (size_t)b * XR + IAF_XP + t;
+                *xp = *xp * s + mean;                                                    // :277
+                float* mp = Mt + (size_t)b * T + t;
+                float* sp = St + (size_t)b * T + t;
+                if (first) { *mp = mean; *sp = s; }
+                else { *mp = mean + *mp * s; *sp = *sp * s; }                            // :322-323
+            }
+        }
+    }
+}
+
+int pick_hn_c(int B, int64_t T, int slots) {
+    const char* force = getenv("WN_HN");
+    if (force) return atoi(force) == 1 ? 1 : 2;
+    if (T % 128) return 1;
+    const int64_t n1 = B * (T / 64), n2 = B * (T / 128);
+    const int64_t c1 = (n1 + slots - 1) / slots, c2 = 2 * ((n2 + slots - 1) / slots);
+    return c1 <= c2 ? 1 : 2;
+}
+
+}  // namespace
+
+int wn_iaf_c_set_attrs(wn_handle* h) {
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_cond_h_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    return WN_OK;
+}
+
+// floats of C per batch row for R row blocks over T samples
+size_t wn_iaf_c_floats(int R, int64_t T) { return (size_t)R * (size_t)(T / 16) * 1024; }
+
+// Conditioning GEMM of the R row blocks listed in rb_off (word offsets of their 8-K-step
+// fragment arrays inside the weight blob) over enc columns [c0, c0+T).
+void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, float* C, int64_t c_bstride,
+                   int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st) {
+    const int tiles_per_row = (int)((T + CK_NC - 1) / CK_NC), ntiles = B * tiles_per_row;
+    constexpr int NW = CK_THREADS / 64;
+    // split the row blocks into chunks so that the persistent grid ends its last round full
+    int best_n = 1;
+    double best_cost = 1e30;
+    for (int nch = 1; nch <= 16; ++nch) {
+        const int ch = ((R + nch - 1) / nch + NW - 1) / NW * NW;
+        if (nch > 1 && (nch - 1) * ch >= R) continue;
+        const int64_t rounds = ((int64_t)ntiles * nch + num_cu - 1) / num_cu;
+        const double cost = (double)rounds * (ch / NW + 0.5);    // +0.5: staging the enc tile
+        if (cost < best_cost) { best_cost = cost; best_n = nch; }
+    }
+    const char* force = getenv("WN_CK_CHUNKS");
+    if (force && atoi(force) > 0) best_n = atoi(force);
+    const int ch = ((R + best_n - 1) / best_n + NW - 1) / NW * NW;
+    const int nchunks = (R + ch - 1) / ch;
+    const int64_t ntasks = (int64_t)ntiles * nchunks;
+    const int grid = (int)std::min<int64_t>(ntasks, num_cu);
+    hipLaunchKernelGGL(iaf_cond_h_kernel, dim3(grid), dim3(CK_THREADS), CK_LDS_BYTES, st,
+                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wblob), rb_off, C,
+                       c_bstride, TE, c0, R, ch, nchunks, tiles_per_row, ntiles, T / 16);
+}
+
+static int lc_slots(int hn) {
+    const char* e = getenv("WN_LC_SLOTS");
+    if (e && atoi(e) > 0) return atoi(e);
+    return hn == 1 ? 2 : 1;
+}
+
+void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
+                    int d, int B, int64_t T, int num_cu, hipStream_t st) {
+    const int hn = pick_hn_c(B, T, 2 * num_cu);
+    const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
+    const int slots = lc_slots(hn) * num_cu;
+    const int grid = ntiles < slots ? ntiles : slots;
+    const char* dbg = getenv("WN_DBG_TILES");
+    const int ntiles_run = dbg ? atoi(dbg) : ntiles;
+    auto kern = hn == 1 ? iaf_layer_c_kernel<1> : iaf_layer_c_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
+                       reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
+                       tiles_per_row, ntiles_run);
+}
+
+void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
+                   float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st) {
+    const int hn = pick_hn_c(B, T, 2 * num_cu);
+    const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
+    const int grid = ntiles < 2 * num_cu ? ntiles : 2 * num_cu;
+    auto kern = hn == 1 ? iaf_head_c_kernel<1> : iaf_head_c_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), HC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin), C,
+                       c_bstride, reinterpret_cast<const unsigned*>(wpack), x, Mt, St, RS, XR, T, first, tiles_per_row,
+                       ntiles);
+}

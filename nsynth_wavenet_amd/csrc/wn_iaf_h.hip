@@ -20,90 +20,9 @@
 #include "wn_internal.h"
 #include "wn_codec.h"
 #include "wn_pack_h.h"
+#include "wn_mfma_h.h"
 
 namespace {
-
-constexpr float EXP_M9 = 1.2340980408667956e-4f;
-constexpr float EXP_7 = 1096.6331584284585f;
-
-__device__ inline f4 mfma_h(wn_u4 a, wn_u4 b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, a), __builtin_bit_cast(wn_h8, b), c, 0, 0, 0);
-}
-__device__ inline f4 mfma3(wn_u4 ah, wn_u4 al, wn_u4 bh, wn_u4 bl, f4 c) {
-    c = mfma_h(ah, bh, c);
-    c = mfma_h(ah, bl, c);
-    return mfma_h(al, bh, c);
-}
-__device__ inline float sigmoidf_(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
-__device__ inline float tanhf_(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * a) + 1.f); }
-
-__device__ inline wn_u2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(wn_u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-__device__ inline void buf_st2(unsigned w0, unsigned w1, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wn_u2, (wn_u2){w0, w1}), r, voff, soff, 0);
-}
-
-template <int NWORDS>
-__device__ inline void stage_words(const unsigned* __restrict__ wpack, unsigned* lds) {
-    constexpr int NV = NWORDS / 4, NCHUNK = NV / 256, REM = NV - NCHUNK * 256;
-    const wn_u4* src = reinterpret_cast<const wn_u4*>(wpack) + threadIdx.x;
-    wn_u4* dst = reinterpret_cast<wn_u4*>(lds) + threadIdx.x;
-    wn_u4 tmp[NCHUNK + 1];
-#pragma unroll
-    for (int k = 0; k < NCHUNK; ++k) tmp[k] = src[k * 256];
-    if (REM && (int)threadIdx.x < REM) tmp[NCHUNK] = src[NCHUNK * 256];
-#pragma unroll
-    for (int k = 0; k < NCHUNK; ++k) dst[k * 256] = tmp[k];
-    if (REM && (int)threadIdx.x < REM) dst[NCHUNK * 256] = tmp[NCHUNK];
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// "G4" activation layout of the split-fp16 path.  A lane's MFMA B operand for K-step s is
-// four words: pair rows 16s + {0,1,8,9} + 2kg.  Those four rows are stored INTERLEAVED:
-//   word(plane, group g = 4s + kg, column t, slot i)  at  ((plane*NG + g)*rowlen + t)*4 + i
-// (NG = 8 groups for the 64 residual channels, 32 for the 256 enc channels), so the operand
-// is ONE aligned 16-byte load per column -- no register shuffling between load and MFMA --
-// and the accumulator layout stores back as full 16-byte words as well (slot = 2*(mb&1)+rp
-// of group 4*(mb>>1) + kg).  Same bytes as the fp32 layout; DRAM sees 256-byte runs.
-struct HSrc {
-    __amdgpu_buffer_rsrc_t rl, re;
-    int vo[3];
-    int ve;
-};
-
-// Tile walk of a persistent workgroup.  Workgroup b runs on XCD b % 8 (observed dispatch
-// order, used for speed only -- any placement is correct); each XCD gets one contiguous eighth
-// of the tiles so that the causal taps t-d, t-2d of a tile mostly hit lines its own L2 already
-// holds (measured 25.5 -> 24.2 us per layer launch at config 2).
-struct TileWalk { int first, end, step; };
-__device__ inline TileWalk tile_walk(int ntiles) {
-#ifndef WN_NO_XCD_TILES
-    if ((gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7, per = (ntiles + 7) >> 3;
-        return {xcd * per + (int)(blockIdx.x >> 3), min(ntiles, (xcd + 1) * per), (int)(gridDim.x >> 3)};
-    }
-#endif
-    return {(int)blockIdx.x, ntiles, (int)gridDim.x};
-}
-
-// operand words of one K-step: hi and lo plane, HN columns
-template <int HN>
-struct KOp {
-    wn_u4 h[HN], l[HN];
-};
-
-#ifndef WN_ENC_AUX
-#define WN_ENC_AUX 0
-#endif
-template <int AUX = 0>
-__device__ inline wn_u4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
-}
-__device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
-}
 
 // ---------------- start conv -> split l  (parallel_wavenet.py:222-225) ----------------
 // One thread = one G4 word group (8 channels) at one time step: consecutive threads write
@@ -287,13 +206,6 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
 }
 
 // ---------------- flow head (parallel_wavenet.py:256-277, :319-324) ----------------
-__device__ inline float softplus_tf(float p) {
-    const float thr = -13.942384719848633f;      // tf.nn.softplus: log(eps) + 2
-    if (p > -thr) return p;
-    if (p < thr) return expf(p);
-    return log1pf(expf(p));
-}
-
 template <int HN>
 __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
     const unsigned* __restrict__ lin, const unsigned* __restrict__ enc, const unsigned* __restrict__ wpack,
@@ -508,6 +420,23 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
             tb[194] = 1.0f / sm;
             tb[195] = 0.f;
         }
+    }
+    // row-block table of the hoisted conditioning GEMM: the cond K-steps of each pack
+    // (layer: K-steps 6-13, head: 2-9) are contiguous 8 x 4 x 2 x 256 words
+    {
+        std::vector<unsigned> tab;
+        for (int k = 0; k < c.n_flows; ++k) {
+            IafFlowPack& fp = h->flows[k];
+            fp.rb_base = (int)tab.size();
+            for (const IafLayerPack& lp : fp.layers) tab.push_back((unsigned)(lp.off_h + 6 * 2048));
+            tab.push_back((unsigned)(fp.head_off_h + 2 * 2048));
+        }
+        if (blob.size() >= 0xffff0000u) return wn_fail(h, WN_EINVAL, "weight blob too large");
+        blob.resize(align_up(blob.size(), 64));
+        h->cond_tab_off = blob.size();
+        h->cond_rows = (int)tab.size();
+        blob.resize(blob.size() + align_up(tab.size(), 4));
+        memcpy(blob.data() + h->cond_tab_off, tab.data(), tab.size() * sizeof(unsigned));
     }
     return WN_OK;
 }

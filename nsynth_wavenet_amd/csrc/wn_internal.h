@@ -49,6 +49,7 @@ struct IafFlowPack {
     size_t head_off;                   // HEAD_FLOATS floats
     size_t head_off_h;                 // split-fp16 head pack
     int deconv_stack;                  // index into wn_handle::stacks
+    int rb_base;                       // first row block of this flow in the hoisted-conditioning table
 };
 
 // Teacher (wn_ar.hip): plain [out][in] row-major matrices
@@ -82,6 +83,10 @@ struct wn_handle {
     std::vector<DeconvStackPack> stacks;
     std::vector<IafFlowPack> flows;
     ArPack ar;
+    // hoisted conditioning (wn_iaf_c.hip): word offsets of the 8-K-step cond fragment arrays of
+    // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
+    size_t cond_tab_off = 0;
+    int cond_rows = 0;
     int frame_shift = 1;
     int num_cu = 256;
     mutable std::string err;
@@ -118,6 +123,10 @@ constexpr int IAF_LAYER_H_WORDS = IAF_P_FLOATS + IAF_PR_FLOATS + 128 + 4;   // +
 // precision of the IAF contractions (wn_config.reserved[0])
 constexpr int WN_PREC_F16X3 = 0;   // split-fp16 on the fp16 MFMA (default)
 constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
+// where the f16x3 path evaluates the per-layer conditioning 1x1s (wn_config.reserved[1])
+constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB Infinity Cache, else fused
+constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
+constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
 
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
@@ -145,6 +154,15 @@ void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float
                     int c0, int d, int B, int64_t T, int num_cu, hipStream_t st);
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
                    int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
+bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T);
+int wn_iaf_c_set_attrs(wn_handle* h);
+size_t wn_iaf_c_floats(int R, int64_t T);
+void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, float* C, int64_t c_bstride,
+                   int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st);
+void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
+                    int d, int B, int64_t T, int num_cu, hipStream_t st);
+void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
+                   float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);

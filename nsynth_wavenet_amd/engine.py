@@ -157,6 +157,10 @@ class Engine(object):
                                            ws.numel(), self._stream()))
         return enc
 
+    def iaf_cond_hoisted(self, batch, num_frames):
+        """True when iaf_generate(batch, num_frames) runs the hoisted-conditioning kernels."""
+        return bool(self.lib.wn_iaf_cond_hoisted(self._h, int(batch), int(num_frames)))
+
     # ---- measurement aid (bench.py) ----
     def profile_begin(self):
         self._check(self.lib.wn_profile_begin(self._h))
