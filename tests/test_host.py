@@ -218,3 +218,39 @@ def test_host_codecs_match_oracle():
     x = np.random.RandomState(0).uniform(-1, 1, 1000).astype(np.float32)
     assert np.array_equal(utils.mu_law_numpy(x), O.mu_law(x))
     assert np.array_equal(utils.cast_quantize_numpy(x, 65536), O.cast_quantize(x, 65536))
+
+
+def test_run_all_eval_staging_and_sweep(tmp_path, monkeypatch):
+    """Local mirror of the reference's run_all_eval.py:36-140: newest checkpoint + config staged with
+    a `checkpoint` state file that latest_checkpoint honours, outputs under waves/<exp>-iter_N,
+    staging directory removed, remote hosts rejected."""
+    import run_all_eval as rae
+    assert rae.get_last_model_prefix(['model.ckpt-5.index', 'model.ckpt-120.index', 'events.x', 'a.json']) == \
+        ('model.ckpt-120', 120)
+    assert rae.get_last_model_prefix(['model.ckpt-7.npz']) == ('model.ckpt-7', 7)
+    with pytest.raises(FileNotFoundError):
+        rae.get_last_model_prefix(['a.json'])
+    exp = tmp_path / 'exp_a'
+    exp.mkdir()
+    for n in ('model.ckpt-10.npz', 'model.ckpt-200.npz', 'events.out.tfevents.1', 'pwn.json'):
+        (exp / n).write_bytes(b'x')
+    target = tmp_path / 'out-01_01_00'
+    model_dir, wave_dir, it = rae.stage_experiment(str(exp), str(target))
+    assert it == 200 and sorted(os.listdir(model_dir)) == ['checkpoint', 'model.ckpt-200.npz', 'pwn.json']
+    assert wave_dir.endswith(os.path.join('waves', 'exp_a-iter_200')) and os.path.isdir(wave_dir)
+    assert os.path.exists(os.path.join(str(target), 'exp_a', 'events.out.tfevents.1'))
+    assert wts.latest_checkpoint(model_dir) == os.path.join(model_dir, 'model.ckpt-200')
+    sweep = tmp_path / 'sweep.json'
+    calls, real_syn_wave = [], rae.syn_wave
+    monkeypatch.setattr(rae, 'syn_wave', lambda *a: calls.append(a) or 0)
+    sweep.write_text(json.dumps({'hosts': [None], 'users': [''], 'passwords': [''], 'exp_dirs': [str(exp)],
+                                 'eval_scripts': ['eval_parallel_wavenet.py']}))
+    out, failed = rae.run_all(str(sweep), str(tmp_path), str(tmp_path / 'out'), '0', stamp='01_01_00')
+    assert failed == [] and len(calls) == 1 and calls[0][0] == 'eval_parallel_wavenet.py'
+    assert calls[0][1] == os.path.join(out, 'exp_a-model') and not os.path.exists(calls[0][1])
+    sweep.write_text(json.dumps({'hosts': ['10.0.0.5'], 'exp_dirs': [str(exp)],
+                                 'eval_scripts': ['eval_wavenet.py']}))
+    with pytest.raises(ValueError):
+        rae.run_all(str(sweep), str(tmp_path), str(tmp_path / 'out'), '0')
+    with pytest.raises(ValueError):
+        real_syn_wave('rm_rf.py', 'a', 'b', 'c', '0')
