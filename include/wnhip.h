@@ -94,11 +94,15 @@ typedef struct wn_config {
     int32_t share_deconv;                   /* use_share_deconv || use_teacher_deconv */
     int32_t use_weight_norm;
     int32_t upsample_act;
-    int32_t reserved[8];                    /* [0] = precision of the IAF / upsampler contractions:
-                                               0 split-fp16 x3 on the fp16 MFMA (default), 1 fp32 MFMA
-                                               [1] = where the split-fp16 path evaluates the per-layer
+    int32_t precision;                      /* IAF / upsampler contractions: 0 split-fp16 x3 on the
+                                               fp16 MFMA (default), 1 fp32 MFMA */
+    int32_t cond_mode;                      /* where the split-fp16 path evaluates the per-layer
                                                conditioning 1x1s: 0 chosen per call from batch x length,
                                                1 inside every layer kernel, 2 one GEMM per deconv stack */
+    int32_t use_resize_conv;                /* upsampler = nearest-neighbour resize + SAME conv
+                                               (masked.py:294-322) instead of transposed conv;
+                                               variables <prefix>resize_conv_i/{W,biases} */
+    int32_t reserved[5];                    /* must be 0 */
 } wn_config;
 
 typedef struct wn_handle wn_handle;

@@ -32,7 +32,8 @@ class WnConfig(ctypes.Structure):
                 ('loss_type', ctypes.c_int32), ('mol_mix', ctypes.c_int32),
                 ('out_width', ctypes.c_int32), ('share_deconv', ctypes.c_int32),
                 ('use_weight_norm', ctypes.c_int32), ('upsample_act', ctypes.c_int32),
-                ('reserved', ctypes.c_int32 * 8)]
+                ('precision', ctypes.c_int32), ('cond_mode', ctypes.c_int32),
+                ('use_resize_conv', ctypes.c_int32), ('reserved', ctypes.c_int32 * 5)]
 
 
 _lib = None

@@ -56,7 +56,7 @@ def iaf_length(hparams, num_frames):
     return (num_frames * frame_shift(hparams) // md) * md
 
 
-# name -> (wn_config.reserved[0] arithmetic, reserved[1] conditioning placement)
+# name -> (wn_config.precision, wn_config.cond_mode)
 PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}
 
 
@@ -76,9 +76,8 @@ def to_wn_config(hparams, kind=None, n_mel=80, precision=None):
     precision = precision or default_precision()
     if precision not in PRECISIONS:
         raise ValueError('precision must be one of {}'.format(sorted(PRECISIONS)))
-    c.reserved[0], c.reserved[1] = PRECISIONS[precision]
-    if getattr(hparams, 'use_resize_conv', False):
-        raise ValueError('use_resize_conv=true is not supported (disabled in every shipped config)')
+    c.precision, c.cond_mode = PRECISIONS[precision]
+    c.use_resize_conv = int(bool(getattr(hparams, 'use_resize_conv', False)))
     dc = hparams.deconv_config
     if len(dc) > _lib.WN_MAX_DECONV:
         raise ValueError('deconv_config has too many layers')

@@ -29,7 +29,7 @@ constexpr int DH_KC = 4;             // K-steps of weights staged in LDS per pip
 
 __host__ __device__ inline int dc_row_stride(int L) {
     // columns: [xoff zeros][L samples][zeros up to the rounded q range + slack]
-    return DC_XOFF + ((L + 2 + DC_QW - 1) / DC_QW) * DC_QW + 8;
+    return DC_XOFF + ((L + 5 + DC_QW - 1) / DC_QW) * DC_QW + 8;
 }
 
 // mel [B,F,C] (reference layout) -> channel-major padded rows [B][C][xs]
@@ -392,10 +392,35 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
             lp.pL = (lp.K - lp.S) / 2;
             lp.taps = lp.K / lp.S;
             if (cin % 16) return wn_fail(h, WN_EINVAL, "deconv: input channels %d not a multiple of 16", cin);
-            std::string scope = (sp.prefix.empty() ? std::string() : sp.prefix + "/") + "trans_conv_" +
-                                std::to_string(j + 1);
-            std::vector<float> W = wn_get_kernel(h, scope, "kernel", true);   // [K][cout][cin]
-            const std::vector<float>& bias = h->vars.at(scope + "/bias").data;
+            std::string scope = (sp.prefix.empty() ? std::string() : sp.prefix + "/") +
+                                (c.use_resize_conv ? "resize_conv_" : "trans_conv_") + std::to_string(j + 1);
+            std::vector<float> W;                                              // [K][cout][cin]
+            if (c.use_resize_conv) {
+                // masked.py:294-322: u[t] = x[t / S] (nearest neighbour), y[t] = b + sum_k u[t+k-pl] Wr[k],
+                // pl = (fl-1)/2 (SAME).  With t + pr = S q + r (pr = fl-1-pl) this is the phase GEMM
+                //   y = sum_j x[q-j] . Weff[S j + r],   Weff[S j + r] = sum_{k: -floor((r+k-(fl-1))/S) = j} Wr[k]
+                // i.e. a transposed conv with the summed kernel Weff, crop offset pr, zeros outside x.
+                const int fl = lp.K, S = lp.S;
+                std::vector<float> Wr = wn_get_kernel(h, scope, "W", false);   // [fl][cin][cout]
+                int taps = (fl - 1 + S - 1) / S + 1;
+                if ((taps * (cin / 16)) % 2) ++taps;                           // even K-step count for the fp16 GEMM
+                lp.taps = taps;
+                lp.K = S * taps;
+                lp.pL = fl - 1 - (fl - 1) / 2;
+                W.assign((size_t)lp.K * lp.cout * cin, 0.f);
+                for (int r = 0; r < S; ++r)
+                    for (int k = 0; k < fl; ++k) {
+                        const int m = r + k - (fl - 1);                        // <= S-1
+                        const int jt = m >= 0 ? 0 : (-m + S - 1) / S;          // -floor(m/S)
+                        for (int co = 0; co < lp.cout; ++co)
+                            for (int ci = 0; ci < cin; ++ci)
+                                W[((size_t)(S * jt + r) * lp.cout + co) * cin + ci] +=
+                                    Wr[((size_t)k * cin + ci) * lp.cout + co];
+                    }
+            } else {
+                W = wn_get_kernel(h, scope, "kernel", true);
+            }
+            const std::vector<float>& bias = h->vars.at(scope + (c.use_resize_conv ? "/biases" : "/bias")).data;
             const int nmb = lp.cout / 16, cblk = cin / 16, nks4 = lp.taps * cblk;
             blob.resize(align_up(blob.size(), 64));
             lp.w_off = blob.size();
@@ -451,7 +476,7 @@ static size_t dc_phase_floats(const wn_handle* h, int B, int F) {
     size_t mx = 0;
     int64_t L = F;
     for (int j = 0; j < c.n_deconv; ++j) {
-        const size_t Qp = (size_t)((L + 2 + DC_QW - 1) / DC_QW) * DC_QW;
+        const size_t Qp = (size_t)((L + 5 + DC_QW - 1) / DC_QW) * DC_QW;   // Q <= L + 5 for <= 8 taps
         mx = std::max(mx, (size_t)B * c.deconv_stride[j] * c.deconv_width * Qp);
         L *= c.deconv_stride[j];
     }
@@ -476,7 +501,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
     const wn_config& c = h->cfg;
     const DeconvStackPack& sp = h->stacks[si];
     // split-fp16 GEMMs when the handle runs in f16x3 mode and every layer's shape supports them
-    bool h_gemm = c.reserved[0] == WN_PREC_F16X3;
+    bool h_gemm = c.precision == WN_PREC_F16X3;
     for (const DeconvLayerPack& lp : sp.layers) h_gemm = h_gemm && lp.w_off_h != 0;
     float* buf = reinterpret_cast<float*>(scratch);
     int xs = dc_row_stride(F);
@@ -508,7 +533,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             y = next; ys = dc_row_stride(Lout); yoff = DC_XOFF;
             WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
         }
-        const int Q = L + 2;
+        const int Q = L + (lp.pL + lp.S - 1) / lp.S + 1;      // phase columns q = (t + pL) / S
         const int Qp = ((Q + DC_QW - 1) / DC_QW) * DC_QW;
         // the fp16 GEMM of the NEXT layer reads G4 words when its input width allows it
         const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);

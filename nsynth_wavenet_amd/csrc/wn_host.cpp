@@ -35,13 +35,19 @@ static void expect_conv(wn_handle* h, const std::string& scope, int K, int cin, 
     expect(h, scope + "/biases", {cout});
 }
 
-// transposed-conv stack variables (masked.py:249-260; names wavenet.py:54-57)
+// upsampler stack variables: transposed conv (masked.py:249-260) or resize + conv
+// (masked.py:294-322, an ordinary conv1d variable pair); names wavenet.py:37-44,54-57
 static void expect_deconv(wn_handle* h, const std::string& prefix) {
     const wn_config& c = h->cfg;
     int cin = c.n_mel;
     for (int j = 0; j < c.n_deconv; ++j) {
         std::string scope = (prefix.empty() ? std::string() : prefix + "/") +
-                            "trans_conv_" + std::to_string(j + 1);
+                            (c.use_resize_conv ? "resize_conv_" : "trans_conv_") + std::to_string(j + 1);
+        if (c.use_resize_conv) {
+            expect_conv(h, scope, c.deconv_filter[j], cin, c.deconv_width);
+            cin = c.deconv_width;
+            continue;
+        }
         if (c.use_weight_norm) {
             expect(h, scope + "/kernel_V", {1, c.deconv_filter[j], c.deconv_width, cin});
             expect(h, scope + "/kernel_g", {c.deconv_width});
@@ -66,6 +72,13 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: deconv_config needs 1..%d layers", WN_MAX_DECONV);
     for (int j = 0; j < c.n_deconv; ++j) {
         int K = c.deconv_filter[j], S = c.deconv_stride[j];
+        if (c.use_resize_conv) {
+            // nearest-neighbour resize + SAME conv == per-phase GEMM with ceil((K-1)/S)+1 taps
+            if (S < 1 || S > 32 || K < 1 || (K - 1 + S - 1) / S + 1 > 7)
+                return wn_fail(nullptr, WN_EINVAL, "config: resize_conv layer %d: stride <= 32 and "
+                               "(filter-1)/stride <= 6 are the supported range, got filter %d stride %d", j, K, S);
+            continue;
+        }
         if (S < 1 || K < S || K % S != 0 || ((K - S) & 1))
             return wn_fail(nullptr, WN_EINVAL,
                            "config: deconv layer %d (filter %d, stride %d) unsupported: need "
@@ -78,12 +91,16 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: n_mel %% 4 and deconv_width %% 64 must be 0");
     if (c.num_stages < 1 || c.num_stages > 10)
         return wn_fail(nullptr, WN_EINVAL, "config: num_stages must be in 1..10");
+    if (c.use_resize_conv != 0 && c.use_resize_conv != 1)
+        return wn_fail(nullptr, WN_EINVAL, "config: use_resize_conv must be 0 or 1");
+    for (int i = 0; i < 5; ++i)
+        if (c.reserved[i]) return wn_fail(nullptr, WN_EINVAL, "config: reserved fields must be 0");
     if (c.upsample_act < 0 || c.upsample_act > 2)
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
-    if (c.reserved[0] != WN_PREC_F16X3 && c.reserved[0] != WN_PREC_F32)
-        return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.reserved[0]);
-    if (c.reserved[1] < WN_COND_AUTO || c.reserved[1] > WN_COND_HOISTED)
-        return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.reserved[1]);
+    if (c.precision != WN_PREC_F16X3 && c.precision != WN_PREC_F32)
+        return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
+    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_HOISTED)
+        return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)
             return wn_fail(nullptr, WN_EINVAL, "config: the IAF kernels tile time in 64-sample blocks and need "

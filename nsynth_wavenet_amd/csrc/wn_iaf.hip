@@ -581,7 +581,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     void* scratch = base + L.scratch;
     const wn_config& c = h->cfg;
 
-    const bool f16x3 = c.reserved[0] == WN_PREC_F16X3;
+    const bool f16x3 = c.precision == WN_PREC_F16X3;
     static bool attr_done = false;
     if (!attr_done) {
         int rc = wn_iaf_h_set_attrs(h);
@@ -600,7 +600,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     // zero left pads
     {
         dim3 g((IAF_LP + 255) / 256, B * IAF_W);
-        if (c.reserved[0] == WN_PREC_F16X3) {
+        if (c.precision == WN_PREC_F16X3) {
             // G4 layout: 16 interleaved group rows per batch element, each 4*(LP+T) words
             dim3 g4((4 * IAF_LP + 255) / 256, B * 16);
             hipLaunchKernelGGL(zero_pad_kernel, g4, dim3(256), 0, st, lA, 4 * L.RS, 4 * IAF_LP, B * 16);
@@ -720,8 +720,8 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 // (1536 B/sample) stay inside the 256 MB Infinity Cache (1-2 utterances of 4.8 s); beyond
 // that the hoisted form is 18-24 % faster.
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
-    if (h->cfg.reserved[0] != WN_PREC_F16X3 || h->cfg.reserved[1] == WN_COND_FUSED) return false;
-    if (h->cfg.reserved[1] == WN_COND_HOISTED) return true;
+    if (h->cfg.precision != WN_PREC_F16X3 || h->cfg.cond_mode == WN_COND_FUSED) return false;
+    if (h->cfg.cond_mode == WN_COND_HOISTED) return true;
     const char* e = getenv("WN_COND");
     if (e && !strcmp(e, "fused")) return false;
     if (e && !strcmp(e, "hoisted")) return true;

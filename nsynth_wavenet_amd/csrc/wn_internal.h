@@ -120,10 +120,10 @@ constexpr int IAF_PH_FLOATS = 80 * 4 * 64;       // 20480
 constexpr int IAF_HEAD_FLOATS = IAF_PH_FLOATS + 64 * 3 + 4;                 // 20676
 
 constexpr int IAF_LAYER_H_WORDS = IAF_P_FLOATS + IAF_PR_FLOATS + 128 + 4;   // + 1/scale_main, 1/scale_res
-// precision of the IAF contractions (wn_config.reserved[0])
+// precision of the IAF contractions (wn_config.precision)
 constexpr int WN_PREC_F16X3 = 0;   // split-fp16 on the fp16 MFMA (default)
 constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
-// where the f16x3 path evaluates the per-layer conditioning 1x1s (wn_config.reserved[1])
+// where the f16x3 path evaluates the per-layer conditioning 1x1s (wn_config.cond_mode)
 constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB Infinity Cache, else fused
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers

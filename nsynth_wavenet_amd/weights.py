@@ -30,8 +30,13 @@ def _conv(out, hp, scope, K, cin, cout):
 
 def _deconv(out, hp, prefix, n_mel):
     cin = n_mel
-    for j, (fl, s) in enumerate(hp.deconv_config):   # wavenet.py:52-67
-        scope = '{}trans_conv_{:d}'.format(prefix + '/' if prefix else '', j + 1)
+    resize = getattr(hp, 'use_resize_conv', False)
+    for j, (fl, s) in enumerate(hp.deconv_config):   # wavenet.py:37-44,52-67
+        scope = '{}{}_{:d}'.format(prefix + '/' if prefix else '', 'resize_conv' if resize else 'trans_conv', j + 1)
+        if resize:                                   # masked.py:294-322: an ordinary conv1d variable pair
+            _conv(out, hp, scope, fl, cin, hp.deconv_width)
+            cin = hp.deconv_width
+            continue
         if getattr(hp, 'use_weight_norm', False):
             out.append((scope + '/kernel_V', (1, fl, hp.deconv_width, cin)))
             out.append((scope + '/kernel_g', (hp.deconv_width,)))
@@ -97,6 +102,8 @@ def synthetic_weights(hp, kind=None, seed=1234, init='tf', n_mel=80):
             elif leaf.startswith('kernel'):
                 stride = dict((fl, s) for fl, s in hp.deconv_config)[shape[1]]
                 std = 1.0 / np.sqrt(shape[3] * shape[1] / stride)
+            elif 'resize_conv' in name:               # the resized input repeats each frame `stride` times
+                std = 1.0 / (shape[1] * np.sqrt(shape[2]))
             else:
                 std = 1.0 / np.sqrt(shape[1] * shape[2])
             w[name] = (rng.standard_normal(shape) * std).astype(np.float32)
@@ -115,7 +122,7 @@ def save_checkpoint(path, weights, hp=None, ema=True):
     """Write an .npz with the key convention the reference's Saver maps use."""
     raw = set()
     if hp is not None and getattr(hp, 'use_teacher_deconv', False):
-        raw = {k for k in weights if k.startswith('iaf_share/trans_conv')}   # parallelgen.py:31-39
+        raw = {k for k in weights if k.startswith(('iaf_share/trans_conv', 'iaf_share/resize_conv'))}   # parallelgen.py:31-39
     out = {}
     for k, v in weights.items():
         out[k if (not ema or k in raw) else k + EMA] = np.asarray(v, np.float32)

@@ -182,6 +182,21 @@ def trans_conv1d(x, W, b, stride, act):
     return act(y) if act is not None else y
 
 
+def resize_conv1d(x, W, b, stride, act):
+    """masked.py:294-322: tf.image.resize_nearest_neighbor along time (src = floor(t / stride)),
+    then the NON-causal branch of conv1d (masked.py:191,209: conv2d SAME, stride 1: zero padding
+    (K-1)//2 on the left, the rest on the right), then activation.  W is HWIO [1,K,Cin,Cout]."""
+    K = W.shape[1]
+    u = np.repeat(x, stride, axis=1)
+    pl = (K - 1) // 2
+    up = np.pad(u, [(0, 0), (pl, K - 1 - pl), (0, 0)])
+    T = u.shape[1]
+    y = np.zeros((x.shape[0], T, W.shape[3]), x.dtype) + b
+    for k in range(K):
+        y = y + up[:, k:k + T] @ W[0, k]
+    return act(y) if act is not None else y
+
+
 def condition(x, cond):
     """wavenet.py:76-85: centre-crop cond to x's length and add."""
     tx, tc = x.shape[1], cond.shape[1]
@@ -191,13 +206,17 @@ def condition(x, cond):
 
 
 def deconv_stack(mel, weights, hp, prefix='', dtype=np.float32):
-    """wavenet.py:46-73,142-155 / parallel_wavenet.py:186-198 (trans_conv branch)."""
-    if hp.get('use_resize_conv', False):
-        raise NotImplementedError('resize_conv is disabled in every shipped config')
+    """wavenet.py:23-73,142-155 / parallel_wavenet.py:186-198 (trans_conv or resize_conv branch)."""
     act = upsample_act(hp.get('upsample_act', 'tanh'))
     wn = hp.get('use_weight_norm', False)
     h = np.asarray(mel, dtype)
     for i, (fl, s) in enumerate(hp.deconv_config):
+        if hp.get('use_resize_conv', False):
+            scope = '{}resize_conv_{:d}'.format(prefix + '/' if prefix else '', i + 1)
+            W = get_kernel(weights, scope, 'W', wn, dtype=dtype)
+            assert W.shape[1] == fl
+            h = resize_conv1d(h, W, np.asarray(weights[scope + '/biases'], dtype), s, act)
+            continue
         scope = '{}trans_conv_{:d}'.format(prefix + '/' if prefix else '', i + 1)
         W = get_kernel(weights, scope, 'kernel', wn, deconv=True, dtype=dtype)
         assert W.shape[1] == fl
@@ -514,6 +533,12 @@ def synth_weights(hp, kind, seed=1234, init='tf'):
     def deconv(prefix):
         cin = n_mel
         for j, (fl, s) in enumerate(hp.deconv_config):
+            if hp.get('use_resize_conv', False):
+                scope = '{}resize_conv_{:d}'.format(prefix, j + 1)
+                w[scope + '/W'] = _mk(rng, [1, fl, cin, dw], 0.05 if init == 'tf' else 1.0 / (fl * np.sqrt(cin)))
+                w[scope + '/biases'] = bias(dw)
+                cin = dw
+                continue
             scope = '{}trans_conv_{:d}'.format(prefix, j + 1)
             w[scope + '/kernel'] = _mk(rng, [1, fl, dw, cin], kstd(cin * fl / s))
             w[scope + '/bias'] = bias(dw)

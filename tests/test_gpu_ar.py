@@ -152,3 +152,27 @@ def test_batched_mfma_step_matches_gemv_step_and_oracle(B, monkeypatch):
         assert np.abs(outs['mfma'][0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     agree = (outs['mfma'][1] == outs['gemv'][1]).mean()
     assert agree > 0.9                       # free-running streams fork only where float noise crosses floor()
+
+
+def test_teacher_resize_conv_encoding():
+    """fastgen.encode path with use_resize_conv=true on the teacher (variables resize_conv_i/{W,biases},
+    odd filter lengths allowed): wn_deconv vs the oracle, then a short teacher-forced run."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = load_json('wavenet_mol.json')
+    cfgd.update(dict(width=128, skip_width=64, deconv_width=64, num_layers=4, num_stages=2,
+                     deconv_config=[[7, 2], [12, 4]], use_resize_conv=True))
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=5, init='unit')
+    assert 'resize_conv_1/W' in w
+    eng = Engine(cfgd).load_weights(w)
+    mel = np.random.RandomState(2).uniform(0, 1, [2, 9, 80]).astype(np.float32)
+    enc = _np(eng.deconv(mel))
+    enc_ref = O.deconv_stack(mel, w, hp, '', np.float64)
+    assert enc.shape == enc_ref.shape == (2, 72, 64)
+    assert np.abs(enc - enc_ref).max() <= 1e-5 * max(1.0, np.abs(enc_ref).max())
+    forced = np.random.RandomState(3).uniform(-1, 1, [2, 72]).astype(np.float32)
+    ref = O.teacher_feed_forward(O.encode_signal(forced, hp, np.float64), enc_ref, w, hp, np.float64)
+    res = eng.ar_generate(enc, forced_wav=forced, want_out=True)
+    assert np.abs(_np(res['out_params']) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    eng.close()

@@ -312,3 +312,32 @@ def test_conditioning_placement_policy():
                           _np(hoisted.iaf_generate(big, nb, want=('x',))['x']))
     for e in (auto, fused, hoisted):
         e.close()
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_resize_conv_upsampler(precision):
+    """use_resize_conv=true (masked.py:294-322; disabled in the shipped JSONs but part of the config
+    surface): nearest-neighbour resize + SAME conv runs as the same per-phase GEMM with a summed
+    kernel.  Student end to end (shared stack, centre crop) and the private-stack variant."""
+    from oracle import wavenet_np as O
+    for extra in ({'use_resize_conv': True}, {'use_resize_conv': True, 'use_share_deconv': False,
+                                               'num_iaf_layers': [10, 10], 'upsample_act': 'tanh'}):
+        cfgd = load_json('parallel_wavenet.json')
+        cfgd.update(extra)
+        hp = O.HP(cfgd)
+        w = O.synth_weights(hp, 'student', seed=7, init='unit')
+        eng = _engine(cfgd, w, precision)
+        rs = np.random.RandomState(3)
+        mel = rs.uniform(0, 1, [2, 11, 80]).astype(np.float32)        # T = 2048, crop 76
+        T = O.iaf_length(11, hp)
+        noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [2, T]))
+        ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+        out = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
+        for k in ('x', 'mean_tot', 'scale_tot'):
+            assert np.abs(_np(out[k]) - ref[k]).max() <= 2e-5 * max(1.0, np.abs(ref[k]).max()), (extra, k)
+        if 'use_share_deconv' not in extra:
+            enc = _np(eng.deconv(mel))
+            enc_ref = O.deconv_stack(mel, w, hp, 'iaf_share', np.float64)
+            assert enc.shape == enc_ref.shape == (2, 2200, 256)
+            assert np.abs(enc - enc_ref).max() <= 1e-5 * max(1.0, np.abs(enc_ref).max())
+        eng.close()

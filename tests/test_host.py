@@ -60,15 +60,18 @@ def test_invalid_configs_are_rejected_by_the_library():
     lib = _lib.load()
     for patch, frag in (({'filter_length': 5}, b'filter_length'), ({'width': 48}, b'specialised'),
                         ({'deconv_config': [[40, 12], [80, 20]]}, b'deconv layer'),
-                        ({'num_stages': 12}, b'num_stages')):
+                        ({'num_stages': 12}, b'num_stages'), ({'num_stages': 5}, b'num_stages >= 7'),
+                        ({'use_resize_conv': True, 'deconv_config': [[80, 10], [80, 20]]}, b'resize_conv layer')):
         d = dict(REFERENCE_STYLE_STUDENT)
         d.update(patch)
         c = cfg.to_wn_config(cfg.load_hparams(d))
         h = ctypes.c_void_p(0)
         assert lib.wn_create(ctypes.byref(c), ctypes.byref(h)) == -22
         assert frag in lib.wn_last_error(None)
-    with pytest.raises(ValueError):
-        cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_resize_conv=True)))
+    assert cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_resize_conv=True))).use_resize_conv == 1
+    c = cfg.to_wn_config(cfg.load_hparams(REFERENCE_STYLE_STUDENT))
+    c.reserved[3] = 1
+    assert lib.wn_create(ctypes.byref(c), ctypes.byref(ctypes.c_void_p(0))) == -22 and b'reserved' in lib.wn_last_error(None)
     with pytest.raises(ValueError):
         cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_teacher_deconv=True)))
 

@@ -211,3 +211,49 @@ def test_golden_codec():
     w8, q8 = O.clip_quant_scale(g['x'], 256, True)
     assert np.array_equal(q16, g['idx16']) and np.array_equal(q8, g['idx8'])
     assert np.array_equal(w16, g['wav16'])
+
+
+@pytest.mark.parametrize('fl,S', [(40, 10), (80, 20), (3, 2), (1, 4), (7, 3), (5, 1)])
+def test_resize_conv_matches_direct_loops_and_phase_gemm_form(fl, S):
+    """masked.py:294-322 (nearest-neighbour resize + non-causal SAME conv): the vectorised
+    restatement equals the definition evaluated sample by sample, and equals the per-phase GEMM
+    with the summed kernel that libwnhip packs (wn_deconv.hip wn_pack_deconv, resize branch)."""
+    rs = np.random.RandomState(fl * 100 + S)
+    L, cin, cout = 6, 3, 2
+    x = rs.standard_normal((2, L, cin))
+    W = rs.standard_normal((1, fl, cin, cout))
+    b = rs.standard_normal(cout)
+    y = O.resize_conv1d(x, W, b, S, None)
+    T, pl = L * S, (fl - 1) // 2
+    direct = np.zeros((2, T, cout)) + b
+    for t in range(T):
+        for k in range(fl):
+            tau = t + k - pl
+            if 0 <= tau < T:
+                direct[:, t] += x[:, tau // S] @ W[0, k]
+    assert np.allclose(y, direct, atol=1e-12)
+    taps, c = (fl - 1 + S - 1) // S + 1, fl - 1 - pl
+    Weff = np.zeros((S * taps, cin, cout))
+    for r in range(S):
+        for k in range(fl):
+            m = r + k - (fl - 1)
+            Weff[S * (0 if m >= 0 else (-m + S - 1) // S) + r] += W[0, k]
+    gemm = np.zeros((2, T, cout)) + b
+    for t in range(T):
+        q, r = divmod(t + c, S)
+        for j in range(taps):
+            if 0 <= q - j < L:
+                gemm[:, t] += x[:, q - j] @ Weff[S * j + r]
+    assert np.allclose(y, gemm, atol=1e-12)
+
+
+def test_resize_conv_student_runs_through_the_oracle():
+    d = load_json('parallel_wavenet.json')
+    d['use_resize_conv'] = True
+    hp = O.HP(d)
+    w = O.synth_weights(hp, 'student', init='unit')
+    assert 'iaf_share/resize_conv_1/W' in w and w['iaf_share/resize_conv_2/W'].shape == (1, 80, 256, 256)
+    assert not any('trans_conv' in k for k in w)
+    mel = np.random.RandomState(0).uniform(0, 1, [1, 3, 80]).astype(np.float32)
+    enc = O.deconv_stack(mel, w, hp, 'iaf_share', np.float64)
+    assert enc.shape == (1, 600, 256) and np.isfinite(enc).all() and 0.05 < enc.std() < 5
