@@ -212,6 +212,17 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
  * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
  * summed elapsed milliseconds and the number of layer-kernel launches they
  * bracket, so that average launch duration = layer_ms / layer_launches. */
+/* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher
+ * handle: wav [B,T] raw audio in [-1,1] (the input encoding of wavenet.py:412-418 -- mu-law/128 when
+ * use_mu_law -- is applied on the device), mel [B,F,n_mel]; out_params [B,T,out_width] are the
+ * logits / mixture parameters the reference returns under 'out_params'.  T <= F*frame_shift (the
+ * conditioning is centre-cropped to T, wavenet.py:76-85) and T must be a multiple of
+ * 2^(num_stages-1) (masked.py:188).  Same result as wn_ar_generate with forced_wav (the reference's
+ * incremental == full-sequence identity), T times fewer dependent launches. */
+size_t wn_teacher_workspace_bytes(const wn_handle* h, int B, int F, int64_t T);
+int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, int B, int F, int64_t T,
+                       float* out_params, void* ws, size_t ws_bytes, void* stream);
+
 /* 1 when wn_iaf_generate(B, F) evaluates the per-layer conditioning 1x1s in one hoisted GEMM per
  * deconv stack (the layer kernels then stream 768 B/sample instead of 1536), else 0. */
 int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);

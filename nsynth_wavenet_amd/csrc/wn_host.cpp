@@ -237,6 +237,9 @@ extern "C" int wn_finalize(wn_handle* h) {
     if (h->cfg.kind == WN_KIND_STUDENT) {
         rc = wn_pack_iaf_h(h, blob);
         if (rc) return rc;
+    } else {
+        rc = wn_pack_teacher(h, blob);
+        if (rc) return rc;
     }
     WN_HIP(h, hipSetDevice(h->device));
     h->blob_floats = blob.size();

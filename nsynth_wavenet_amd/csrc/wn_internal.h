@@ -73,6 +73,22 @@ struct ArPack {
     size_t ring_floats;        // per batch element
 };
 
+// Full-sequence teacher forward (wn_teacher.hip): split-fp16 A fragments in 64-row tiles
+struct TeacherGemmPack {
+    size_t w_off = 0;      // [m-tile][K-step][4 row blocks][plane][lane][4] words
+    size_t b_off = 0;      // [m-tile][64] bias, tile-local row order
+    float inv_scale = 1.f;
+    int nks = 0, mtiles = 0;
+};
+struct TeacherLayerPack {
+    TeacherGemmPack gate, rs;
+    int dilation;
+};
+struct TeacherPack {
+    TeacherGemmPack skip_start, out1, out2;
+    std::vector<TeacherLayerPack> layers;
+};
+
 struct wn_handle {
     wn_config cfg;
     std::map<std::string, HostTensor> vars;   // expected variables (+ data once set)
@@ -83,6 +99,7 @@ struct wn_handle {
     std::vector<DeconvStackPack> stacks;
     std::vector<IafFlowPack> flows;
     ArPack ar;
+    TeacherPack teacher;
     // hoisted conditioning (wn_iaf_c.hip): word offsets of the 8-K-step cond fragment arrays of
     // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
     size_t cond_tab_off = 0;
@@ -135,6 +152,7 @@ constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_l
 int wn_pack_deconv(wn_handle* h, std::vector<float>& blob);
 int wn_pack_iaf(wn_handle* h, std::vector<float>& blob);
 int wn_pack_ar(wn_handle* h, std::vector<float>& blob);
+int wn_pack_teacher(wn_handle* h, std::vector<float>& blob);   // after wn_pack_ar (reuses its matrices)
 
 // Runs stack `si` on mel [B,F,n_mel]; writes channel-major enc [B][cout][enc_stride]
 // (first valid sample at column 0).  Scratch carved from ws.

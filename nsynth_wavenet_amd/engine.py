@@ -157,6 +157,25 @@ class Engine(object):
                                            ws.numel(), self._stream()))
         return enc
 
+    # ---- teacher, whole sequence at once ----
+    def teacher_forward(self, wav, mel):
+        """Wavenet.feed_forward (wavenet.py:180-291): wav [B,T] raw audio, mel [B,F,n_mel] ->
+        out_params [B,T,out_width].  T <= F*frame_shift, multiple of the largest dilation."""
+        wav, mel = self._dev(wav), self._dev(mel)
+        if wav.dim() != 2 or mel.dim() != 3 or wav.shape[0] != mel.shape[0]:
+            raise ValueError('teacher_forward: wav must be [B,T] and mel [B,F,n_mel] with equal B')
+        if int(mel.shape[2]) != self.n_mel:
+            raise ValueError('teacher_forward: mel has {} channels, the model expects {}'.format(
+                int(mel.shape[2]), self.n_mel))
+        B, T, F = int(wav.shape[0]), int(wav.shape[1]), int(mel.shape[1])
+        out = torch.empty((B, T, cfg.teacher_out_width(self.hp)), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nb = self.lib.wn_teacher_workspace_bytes(self._h, B, F, T)
+            ws = self._workspace(max(int(nb), 256))
+            self._check(self.lib.wn_teacher_forward(self._h, _ptr(wav), _ptr(mel), B, F, T, _ptr(out), _ptr(ws),
+                                                    ws.numel(), self._stream()))
+        return out
+
     def iaf_cond_hoisted(self, batch, num_frames):
         """True when iaf_generate(batch, num_frames) runs the hoisted-conditioning kernels."""
         return bool(self.lib.wn_iaf_cond_hoisted(self._h, int(batch), int(num_frames)))

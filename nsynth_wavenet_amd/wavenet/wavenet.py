@@ -32,10 +32,19 @@ class _TeacherBase(object):
 
 
 class Wavenet(_TeacherBase):
-    """Only the part of the teacher the generation path uses: the upsampler."""
+    """The teacher's inference graphs: the upsampler and the full-sequence forward."""
 
     def deconv_stack(self, mel_inputs, init=False):
         return {'encoding': self.engine.deconv(mel_inputs['mel'])}
+
+    def feed_forward(self, inputs, init=False):
+        """wavenet.py:180-291 with 'wav' [B,T] raw audio and 'mel' [B,F,80]: the reference derives
+        'wav_scaled' from 'wav' (wavenet.py:157-178); here the device does.  Returns 'out_params'
+        [B,T,out_width] (and 'encoding' on request through deconv_stack: it is not materialised
+        in the reference layout by this call)."""
+        if init:
+            raise ValueError('data-dependent initialisation is a training-time feature')
+        return {'out_params': self.engine.teacher_forward(inputs['wav'], inputs['mel'])}
 
 
 class Fastgen(_TeacherBase):
