@@ -275,6 +275,133 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_h_kernel(
         }
 }
 
+// G4-input variant that loads every activation column ONCE per 32-channel block: tap j of the
+// transposed conv reads the same rows one column to the left of tap j-1, and a lane owns DC_NT
+// consecutive columns, so the shifted operand is a register renaming (e -> e+1) plus one
+// row_shr:1 DPP move per word for e = 0, with the column left of the wave's range ("halo")
+// patched into lane 0 of each 16-lane row.  K is walked block-major (all taps of a block, then
+// the next block); the A fragments of those K-steps are staged together.  4x less operand
+// traffic than reloading per tap (the plain kernel is bound by it, not by the MFMA pipe).
+__device__ inline unsigned dpp_shr1(unsigned old, unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false);   // row_shr:1
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
+    const unsigned* __restrict__ x, int cin, int xs, const unsigned* __restrict__ wp,
+    float* __restrict__ yp, int cout, int Qp, int S, float inv_scale) {
+    constexpr int taps = TAPS, NH = TAPS > 1 ? TAPS - 1 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2][DH_KC * 4 * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kg = lane >> 4;
+    const int r = blockIdx.y;
+    const int ncg = cout / 64;
+    const int b = blockIdx.z / ncg, cg = blockIdx.z % ncg;
+    const int q0 = blockIdx.x * DC_QW + wave * DC_QT;
+    const int nmb = cout / 16;
+    const int nb32 = cin / 32;                     // 32-channel blocks
+    const int nks = taps * nb32;                   // K-step ks = tap * nb32 + block (pack order)
+    constexpr int ntg = (taps + DH_KC - 1) / DH_KC;   // tap groups per block (one LDS stage each)
+    const int nchunk = nb32 * ntg;
+
+    f4 acc[4][DC_NT];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int e = 0; e < DC_NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const wn_u4* wsrc = reinterpret_cast<const wn_u4*>(wp);       // [r][ks][mb][plane][lane] u4
+    auto stage = [&](int chunk, int buf) {
+        const int c = chunk / ntg, tg = chunk - c * ntg;
+#pragma unroll
+        for (int kl = 0; kl < DH_KC; ++kl) {
+            const int j = tg * DH_KC + kl;
+            if (j < taps) {
+                const wn_u4* src = wsrc + (((size_t)r * nks + j * nb32 + c) * nmb + cg * 4) * 128;
+                wn_u4* dst = reinterpret_cast<wn_u4*>(lds[buf]) + kl * 512;
+                dst[threadIdx.x] = src[threadIdx.x];
+                dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+            }
+        }
+    };
+    const unsigned* xb = x + (size_t)b * cin * xs;
+    const size_t lo_plane = (size_t)(cin / 2) * xs;
+    // tap-0 operands of block c (DC_NT consecutive columns per lane) and the halo columns q0-1 .. q0-7
+    auto loadB = [&](int c, wn_u4 (&vh)[DC_NT], wn_u4 (&vl)[DC_NT], wn_u4 (&hh)[NH], wn_u4 (&hl)[NH]) {
+        const unsigned* row = xb + ((size_t)(4 * c + kg) * xs + DC_XOFF + q0) * 4;
+        const unsigned* p = row + DC_NT * n * 4;
+#pragma unroll
+        for (int e = 0; e < DC_NT; ++e) {
+            vh[e] = *reinterpret_cast<const wn_u4*>(p + 4 * e);
+            vl[e] = *reinterpret_cast<const wn_u4*>(p + lo_plane + 4 * e);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < taps; ++k) {
+            hh[k] = *reinterpret_cast<const wn_u4*>(row - 4 * (k + 1));
+            hl[k] = *reinterpret_cast<const wn_u4*>(row + lo_plane - 4 * (k + 1));
+        }
+    };
+
+    stage(0, 0);
+    wn_u4 nh[DC_NT], nl[DC_NT], nhh[NH], nhl[NH];    // next block's operands, one block ahead
+    loadB(0, nh, nl, nhh, nhl);
+    __syncthreads();
+    wn_u4 vh[DC_NT], vl[DC_NT], hh[NH], hl[NH];
+    for (int c = 0; c < nb32; ++c) {
+#pragma unroll
+        for (int e = 0; e < DC_NT; ++e) { vh[e] = nh[e]; vl[e] = nl[e]; }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) { hh[k] = nhh[k]; hl[k] = nhl[k]; }
+        if (c + 1 < nb32) loadB(c + 1, nh, nl, nhh, nhl);
+#pragma unroll
+      for (int tg = 0; tg < ntg; ++tg) {
+        const int chunk = c * ntg + tg;
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunk) stage(chunk + 1, buf ^ 1);
+        const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
+#pragma unroll
+        for (int kl = 0; kl < DH_KC; ++kl) {
+            const int j = tg * DH_KC + kl;
+            if (j >= taps) break;
+            if (j > 0) {
+                // operands one column to the left: e -> e+1, e = 0 from the neighbour lane / halo
+                const wn_u4 th = vh[DC_NT - 1], tl = vl[DC_NT - 1];
+#pragma unroll
+                for (int e = DC_NT - 1; e > 0; --e) { vh[e] = vh[e - 1]; vl[e] = vl[e - 1]; }
+                const wn_u4 oh = hh[j > 0 ? j - 1 : 0], ol = hl[j > 0 ? j - 1 : 0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vh[0][i] = dpp_shr1(oh[i], th[i]);
+                    vl[0][i] = dpp_shr1(ol[i], tl[i]);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const wn_u4 ah = Al[(kl * 4 + mb) * 128], al = Al[(kl * 4 + mb) * 128 + 64];
+#pragma unroll
+                for (int e = 0; e < DC_NT; ++e) {
+                    f4 cc = acc[mb][e];
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
+                    acc[mb][e] = cc;
+                }
+            }
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = 64 * cg + 16 * mb + 4 * kg + rr;
+            float* row = yp + (((size_t)b * S + r) * cout + co) * Qp + q0 + DC_NT * n;
+            *reinterpret_cast<f4*>(row) = (f4){acc[mb][0][rr] * inv_scale, acc[mb][1][rr] * inv_scale,
+                                               acc[mb][2][rr] * inv_scale, acc[mb][3][rr] * inv_scale};
+        }
+}
+
 // channel-major [B][C][T] (row stride cs) -> reference layout [B][T][C]
 __global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict__ out,
                                 int C, int64_t T, int64_t cs) {
@@ -539,10 +666,25 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);
         if (h_gemm) {
             dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
-            auto kern = in_g4 ? deconv_mfma_h_kernel<true> : deconv_mfma_h_kernel<false>;
-            hipLaunchKernelGGL(kern, g, dim3(256), 0, st, reinterpret_cast<const unsigned*>(x), lp.cin, xs,
-                               reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h), phase, lp.cout, Qp, lp.S,
-                               lp.taps, lp.inv_scale_h);
+            static const bool no_shift = getenv("WN_DECONV_NOSHIFT") != nullptr;
+            const unsigned* xin = reinterpret_cast<const unsigned*>(x);
+            const unsigned* wfr = reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h);
+            // G4 input: every column is loaded once per channel block and shifted in registers for the
+            // other taps (instantiated for the tap counts of the supported configs)
+            if (in_g4 && !no_shift && lp.taps == 4)
+                hipLaunchKernelGGL(deconv_mfma_hs_kernel<4>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
+                                   Qp, lp.S, lp.inv_scale_h);
+            else if (in_g4 && !no_shift && lp.taps == 5)
+                hipLaunchKernelGGL(deconv_mfma_hs_kernel<5>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
+                                   Qp, lp.S, lp.inv_scale_h);
+            else if (in_g4 && !no_shift && lp.taps == 6)
+                hipLaunchKernelGGL(deconv_mfma_hs_kernel<6>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
+                                   Qp, lp.S, lp.inv_scale_h);
+            else {
+                auto kern = in_g4 ? deconv_mfma_h_kernel<true> : deconv_mfma_h_kernel<false>;
+                hipLaunchKernelGGL(kern, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout, Qp, lp.S, lp.taps,
+                                   lp.inv_scale_h);
+            }
         } else {
             const int zc = (lp.cout + 255) / 256;
             dim3 g(Qp / DC_QT, lp.S, B * zc);

@@ -1,5 +1,5 @@
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-for b in 1 8; do for p in f16x3-fused f16x3-hoisted; do
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --batch-per-gpu $b --precision $p 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$b $p', round(d['value']/1e6,2),'Ms/s', round(d['ms_per_step'],3),'ms', d['roofline']['kernel'][:20], round(d['roofline']['achieved']), round(d['roofline']['frac'],3), round(d['roofline']['avg_launch_us'],2))"
-done; done
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/var_dc -o v -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /root/repo/gpurun_out/var_dc.log 2>&1
+grep -E "deconv|interleave" /root/repo/gpurun_out/var_dc/v_kernel_stats.csv | sed -E 's/\(unsigned[^"]*"/"/;s/\(float[^"]*"/"/' | cut -d, -f1,2,4
+tail -1 /root/repo/gpurun_out/var_dc.log | cut -c1-160
