@@ -311,16 +311,29 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
         for (int e = 0; e < DC_NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const wn_u4* wsrc = reinterpret_cast<const wn_u4*>(wp);       // [r][ks][mb][plane][lane] u4
-    auto stage = [&](int chunk, int buf) {
+    // weight fragments of a chunk: global -> registers at the start of the previous chunk, registers ->
+    // LDS at its end, so the L2 latency is covered by that chunk's MFMAs
+    wn_u4 wt[DH_KC][2];
+    auto stage_load = [&](int chunk) {
         const int c = chunk / ntg, tg = chunk - c * ntg;
 #pragma unroll
         for (int kl = 0; kl < DH_KC; ++kl) {
             const int j = tg * DH_KC + kl;
             if (j < taps) {
                 const wn_u4* src = wsrc + (((size_t)r * nks + j * nb32 + c) * nmb + cg * 4) * 128;
+                wt[kl][0] = src[threadIdx.x];
+                wt[kl][1] = src[threadIdx.x + 256];
+            }
+        }
+    };
+    auto stage_store = [&](int chunk, int buf) {
+        const int c = chunk / ntg, tg = chunk - c * ntg;
+#pragma unroll
+        for (int kl = 0; kl < DH_KC; ++kl) {
+            if (tg * DH_KC + kl < taps) {
                 wn_u4* dst = reinterpret_cast<wn_u4*>(lds[buf]) + kl * 512;
-                dst[threadIdx.x] = src[threadIdx.x];
-                dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+                dst[threadIdx.x] = wt[kl][0];
+                dst[threadIdx.x + 256] = wt[kl][1];
             }
         }
     };
@@ -342,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
         }
     };
 
-    stage(0, 0);
+    stage_load(0);
+    stage_store(0, 0);
     wn_u4 nh[DC_NT], nl[DC_NT], nhh[NH], nhl[NH];    // next block's operands, one block ahead
     loadB(0, nh, nl, nhh, nhl);
     __syncthreads();
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
       for (int tg = 0; tg < ntg; ++tg) {
         const int chunk = c * ntg + tg;
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunk) stage(chunk + 1, buf ^ 1);
+        if (chunk + 1 < nchunk) stage_load(chunk + 1);
         const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
 #pragma unroll
         for (int kl = 0; kl < DH_KC; ++kl) {
@@ -388,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
                 }
             }
         }
+        if (chunk + 1 < nchunk) stage_store(chunk + 1, buf ^ 1);
         __syncthreads();
       }
     }

@@ -79,10 +79,17 @@ __global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __
 }
 
 // zero the left pads of `rows` rows (row stride rs floats, pad floats each)
-__global__ void zero_pad_kernel(float* __restrict__ p, int64_t rs, int pad, int rows) {
+// zero left pads of both activation buffers and of the flow input, one launch (blockIdx.z picks)
+__global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
+                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows) {
     const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
+    if (blockIdx.z < 2) {
+        float* p = blockIdx.z ? lB : lA;
+        if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
+    } else if (row < xrows && c < xpad) {
+        x[(size_t)row * xrs + c] = 0.f;
+    }
 }
 
 // ---------------- start conv (parallel_wavenet.py:222-225; masked.py:39-52) ----------------
@@ -599,17 +606,12 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
 
     // zero left pads
     {
-        dim3 g((IAF_LP + 255) / 256, B * IAF_W);
-        if (c.precision == WN_PREC_F16X3) {
-            // G4 layout: 16 interleaved group rows per batch element, each 4*(LP+T) words
-            dim3 g4((4 * IAF_LP + 255) / 256, B * 16);
-            hipLaunchKernelGGL(zero_pad_kernel, g4, dim3(256), 0, st, lA, 4 * L.RS, 4 * IAF_LP, B * 16);
-            hipLaunchKernelGGL(zero_pad_kernel, g4, dim3(256), 0, st, lB, 4 * L.RS, 4 * IAF_LP, B * 16);
-        } else {
-            hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lA, L.RS, IAF_LP, B * IAF_W);
-            hipLaunchKernelGGL(zero_pad_kernel, g, dim3(256), 0, st, lB, L.RS, IAF_LP, B * IAF_W);
-        }
-        hipLaunchKernelGGL(zero_pad_kernel, dim3(1, B), dim3(256), 0, st, x, (int64_t)L.XR, IAF_XP, B);
+        // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
+        const int rows = f16x3 ? B * 16 : B * IAF_W;
+        const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
+        const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
+        dim3 g((pad + 255) / 256, rows, 3);
+        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B);
     }
     // noise
     const float* x0 = noise;
