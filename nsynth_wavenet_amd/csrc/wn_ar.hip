@@ -445,7 +445,6 @@ __global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
     const int g0 = MODE == 4 ? 16 * blockIdx.z : 0, g1 = MODE == 4 ? min(nks4, g0 + 16) : nks4;
     const int per = (g1 - g0 + nw - 1) / nw;
     const int k4a = g0 + wave * per, k4b = min(g1, k4a + per);
-    const int nslab = (3 * D.W + D.Cd + 255) / 256;
 
     const float* ring = state + L.rings + ring_off * NB;
     const size_t slot2 = (size_t)(t % (2 * dil)) * D.W, slot1 = (size_t)((t + dil) % (2 * dil)) * D.W;

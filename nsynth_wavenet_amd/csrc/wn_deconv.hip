@@ -681,18 +681,17 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);
         if (h_gemm) {
             dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
-            static const bool no_shift = getenv("WN_DECONV_NOSHIFT") != nullptr;
             const unsigned* xin = reinterpret_cast<const unsigned*>(x);
             const unsigned* wfr = reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_h);
             // G4 input: every column is loaded once per channel block and shifted in registers for the
             // other taps (instantiated for the tap counts of the supported configs)
-            if (in_g4 && !no_shift && lp.taps == 4)
+            if (in_g4 && lp.taps == 4)
                 hipLaunchKernelGGL(deconv_mfma_hs_kernel<4>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
                                    Qp, lp.S, lp.inv_scale_h);
-            else if (in_g4 && !no_shift && lp.taps == 5)
+            else if (in_g4 && lp.taps == 5)
                 hipLaunchKernelGGL(deconv_mfma_hs_kernel<5>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
                                    Qp, lp.S, lp.inv_scale_h);
-            else if (in_g4 && !no_shift && lp.taps == 6)
+            else if (in_g4 && lp.taps == 6)
                 hipLaunchKernelGGL(deconv_mfma_hs_kernel<6>, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout,
                                    Qp, lp.S, lp.inv_scale_h);
             else {

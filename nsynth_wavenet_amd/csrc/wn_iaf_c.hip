@@ -490,8 +490,6 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
         const double cost = (double)rounds * (ch / NW + 0.5);    // +0.5: staging the enc tile
         if (cost < best_cost) { best_cost = cost; best_n = nch; }
     }
-    const char* force = getenv("WN_CK_CHUNKS");
-    if (force && atoi(force) > 0) best_n = atoi(force);
     const int ch = ((R + best_n - 1) / best_n + NW - 1) / NW * NW;
     const int nchunks = (R + ch - 1) / ch;
     const int64_t ntasks = (int64_t)ntiles * nchunks;
@@ -501,11 +499,9 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
                        c_bstride, TE, c0, R, ch, nchunks, tiles_per_row, ntiles, T / 16);
 }
 
-static int lc_slots(int hn) {
-    const char* e = getenv("WN_LC_SLOTS");
-    if (e && atoi(e) > 0) return atoi(e);
-    return hn == 1 ? 2 : 1;
-}
+// workgroups per CU of the hoisted layer / head kernels (57 KB of LDS; the 128-column variant
+// needs the whole register file)
+static int lc_slots(int hn) { return hn == 1 ? 2 : 1; }
 
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
                     int d, int B, int64_t T, int num_cu, hipStream_t st) {
@@ -513,12 +509,10 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int slots = lc_slots(hn) * num_cu;
     const int grid = ntiles < slots ? ntiles : slots;
-    const char* dbg = getenv("WN_DBG_TILES");
-    const int ntiles_run = dbg ? atoi(dbg) : ntiles;
     auto kern = hn == 1 ? iaf_layer_c_kernel<1> : iaf_layer_c_kernel<2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
-                       tiles_per_row, ntiles_run);
+                       tiles_per_row, ntiles);
 }
 
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,

@@ -472,8 +472,7 @@ void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float
                     int c0, int d, int B, int64_t T, int num_cu, hipStream_t st) {
     const int hn = pick_hn(B, T, num_cu);
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
-    int grid = ntiles < num_cu ? ntiles : num_cu;
-    if (const char* dg = getenv("WN_DBG_GRID")) grid = std::min(grid, atoi(dg));
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
     auto kern = hn == 1 ? iaf_layer_h_kernel<1> : iaf_layer_h_kernel<2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st,
                        reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout),
