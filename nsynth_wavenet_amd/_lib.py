@@ -48,6 +48,9 @@ def load():
         raise RuntimeError(
             'libwnhip.so not found at {}: build it with `python -m nsynth_wavenet_amd.build` '
             '(there is no CPU fallback for the generation path)'.format(LIB_PATH))
+    # PyTorch-ROCm ships its own HIP runtime; load it first so that libwnhip.so binds to the same
+    # libamdhip64 instance torch uses (two runtimes in one process do not share devices or streams)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, i32, i64, u64, sz = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_size_t
