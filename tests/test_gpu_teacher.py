@@ -79,3 +79,17 @@ def test_full_width_teacher_forward():
     one = _np(net.feed_forward({'wav': wav[1:], 'mel': mel[1:]})['out_params'])
     assert np.array_equal(one[0], out[1])
     net.engine.close()
+
+
+def test_forward_with_fp32_upsampler_handle():
+    """A teacher handle created with precision='f32' runs its upsampler on the fp32 MFMA; the layer
+    GEMMs of the full-sequence forward stay split-fp16.  Same parity bar."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, 'ar_mol.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    w = O.synth_weights(O.HP(cfgd), 'teacher', seed=1234, init='unit')
+    eng = Engine(cfgd, precision='f32').load_weights(w)
+    out = _np(eng.teacher_forward(g['forced'], g['mel']))
+    assert np.abs(out - g['out_forced']).max() <= 2e-5 * max(1.0, np.abs(g['out_forced']).max())
+    eng.close()
