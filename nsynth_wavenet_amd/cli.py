@@ -73,6 +73,9 @@ def mel_batch(batch_files, sample_length):
         if data.ndim != 3:
             raise ValueError('.npy inputs must be mel arrays [frames, {}]'.format(mel_extractor.NUM_MEL))
         return data.astype(np.float32)
+    import torch
+    if torch.cuda.is_available():          # featurise on the device the generation runs on
+        return mel_extractor.batch_melspectrogram_device(data)
     return mel_extractor.batch_melspectrogram(data)
 
 

@@ -60,7 +60,9 @@ def encode(hparams, wav_data, checkpoint_path):
     wav_data = np.asarray(wav_data)
     if wav_data.ndim == 1:
         wav_data = np.expand_dims(wav_data, 0)
-    mel_val = mel_extractor.batch_melspectrogram(wav_data)
+    import torch
+    mel_val = mel_extractor.batch_melspectrogram_device(wav_data) if torch.cuda.is_available() \
+        else mel_extractor.batch_melspectrogram(wav_data)
     return encode_mel(hparams, mel_val, checkpoint_path)
 
 

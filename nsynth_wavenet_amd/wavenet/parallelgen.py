@@ -40,7 +40,10 @@ def generate(hparams, mel, checkpoint_path, noise=None, seed=None):
     eng = load_parallelgen(hparams, checkpoint_path)
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))       # the reference's draws are unseeded
-    mel_d = torch.as_tensor(np.ascontiguousarray(mel), dtype=torch.float32).to(eng.device)
+    if torch.is_tensor(mel):                                # already featurised on the device
+        mel_d = mel.to(device=eng.device, dtype=torch.float32).contiguous()
+    else:
+        mel_d = torch.as_tensor(np.ascontiguousarray(mel), dtype=torch.float32).to(eng.device)
     torch.cuda.synchronize(eng.device)
     start = time.time()
     out = eng.iaf_generate(mel_d, noise=noise, seed=seed, want=('wav',))

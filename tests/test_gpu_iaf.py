@@ -341,3 +341,18 @@ def test_resize_conv_upsampler(precision):
             assert enc.shape == enc_ref.shape == (2, 2200, 256)
             assert np.abs(enc - enc_ref).max() <= 1e-5 * max(1.0, np.abs(enc_ref).max())
         eng.close()
+
+
+def test_device_mel_featuriser_matches_host_featuriser():
+    """auxilaries/mel_extractor.py: the GPU featuriser (rocFFT + matmul) against the numpy restatement
+    on noise, a tone and silence, including the reference fixture length (154 480 samples -> 773 frames)."""
+    import torch
+    from nsynth_wavenet_amd.auxilaries import mel_extractor as M
+    rs = np.random.RandomState(0)
+    t = np.arange(154480) / 16000.0
+    wavs = np.stack([rs.uniform(-0.5, 0.5, 154480), 0.3 * np.sin(2 * np.pi * 440.0 * t), np.zeros(154480)]).astype(np.float32)
+    dev = M.batch_melspectrogram_device(wavs)
+    assert dev.is_cuda and tuple(dev.shape) == (3, 773, 80) and dev.dtype == torch.float32
+    host = M.batch_melspectrogram(wavs)
+    assert np.abs(_np(dev) - host).max() <= 2e-4
+    assert float(dev[2].max()) == float(host[2].max())          # silence sits on the floor (40/140)
