@@ -12,10 +12,13 @@
 // graph) and replayed; no host round trip per sample.
 //
 // Two step implementations, chosen by batch size:
-//  * B < 4: wave-per-output-row GEMV kernels, activations [batch][feature];
+//  * B < 4: wave-per-output-row GEMV kernels, activations [batch][feature], ONE launch per
+//    layer (ar_layer_m_kernel: the residual update is substituted into the next layer's
+//    current-tap term, so a layer is a single dependent phase) -- 35 launches per step;
 //  * B >= 4: the batch is the N dimension of v_mfma_f32_16x16x4_f32 (activations
-//    [feature][padded batch]), so one pass over the 119 MB of weights serves every utterance.
-// Both are chains of ~62-92 dependent, latency-bound launches per step.
+//    [feature][padded batch]), so one pass over the 119 MB of weights serves every utterance
+//    (three launches per layer, ~95 per step).
+// Both are chains of dependent, launch-latency-bound kernels.
 #include <cstdlib>
 #include <cstring>
 
@@ -35,7 +38,7 @@ struct ArDims {
 
 // State blob (floats): [hdr 64][a_prev B][u ring 4*B][rings...][l B*W][s B*S][g B*G/2][z B*S][out B*OW][ebuf B*OW]
 struct ArStateLayout {
-    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, encT, slab, total;
+    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, encT, slab, l2, dbuf, total;
     int NB;      // 0: GEMV layout [batch][feature]; >0: MFMA layout [feature][NB] (NB = padded batch)
 };
 
@@ -68,6 +71,9 @@ ArStateLayout ar_state_layout(const wn_handle* h, int B) {
     L.encT = carve(Bp * c.deconv_width);
     // K-split partial pre-activations of the gate GEMM: [ceil(K/256)][gate_width][NB]
     L.slab = carve(L.NB ? (size_t)((3 * c.width + c.deconv_width + 255) / 256) * c.gate_width * Bp : 0);
+    // merged GEMV step: second residual-stream buffer and two pre-activation buffers (ping-pong per layer)
+    L.l2 = carve(L.NB ? 0 : (size_t)B * c.width);
+    L.dbuf = carve(L.NB ? 0 : 2 * (size_t)B * c.gate_width);
     L.total = o;
     return L;
 }
@@ -258,6 +264,243 @@ __global__ __launch_bounds__(256) void ar_gate_kernel(
         }
         __syncthreads();
     }
+}
+
+// =====================  merged GEMV step (B < 4): one launch per layer  =====================
+// A layer needs two dependent phases (pre-activation -> gate -> res/skip), and the step is a chain
+// of launch-latency-bound kernels (~4.7 us each), so the count of dependent launches IS the step
+// time.  With lin_j = lin_{j-1} + Wres_{j-1} m_{j-1} + bres_{j-1} substituted into the current-tap
+// term of layer j,
+//   d_j = Wd_j[t-2d] ring_j(t-2d) + Wd_j[t-d] ring_j(t-d) + Wd_j[t] lin_{j-1} + (Wd_j[t] Wres_{j-1}) m_{j-1}
+//         + Wc_j enc + (bd_j + bc_j + Wd_j[t] bres_{j-1}),
+// every row of {lin_j, s += skip_{j-1}, d_j} depends only on lin_{j-1}, d_{j-1} (m_{j-1} = gate(d_{j-1})
+// is recomputed by every workgroup: 512 sigmoid*tanh) and on ring / enc data of earlier steps:
+// ONE kernel per layer, 34 launches per step instead of 65.  Same arithmetic up to fp32
+// re-association of the current-tap term; lin_j itself is computed exactly as before.
+//   rings: slot = step mod (2d+1), so the slot pushed at step t is not the one holding t-2d.
+
+// One GEMV row with every global load issued before the first use: the weights of the row
+// (NC chunks of 256 floats, one f4 per lane each) are loaded up front -- before the prologue of
+// the kernel even starts -- and so are the inputs that live in global memory; inputs produced by
+// the prologue come from LDS afterwards.  The kernels are one or two memory round trips long, so
+// the number of SEQUENTIAL round trips is what matters.
+constexpr int AR_NCA = 8;    // chunks of the dilated + cond row (3W + Cd <= 2048, checked in wn_pack_ar)
+constexpr int AR_NCH = 4;    // chunks of an H-long row (gate_width / 2 <= 1024)
+constexpr int AR_GEMV_MAXB = 3;   // the GEMV step serves batches below 4 (ar_padded_batch)
+
+// sigmoid(a) * tanh(b) with the hardware exp / rcp (abs error ~1e-7, as in the IAF kernels)
+__device__ inline float ar_gate(float a, float b) {
+#ifdef WN_AR_LIBM_GATE
+    return (1.f / (1.f + expf(-a))) * tanhf(b);
+#else
+    return __builtin_amdgcn_rcpf(1.f + __expf(-a)) * (1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * b) + 1.f));
+#endif
+}
+
+template <int NC>
+struct RowW {
+    f4 w[NC];
+};
+template <int NC>
+__device__ inline RowW<NC> row_load(const float* __restrict__ wrow, int K, int lane) {
+    RowW<NC> r;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int k = i * 256 + lane * 4;
+        r.w[i] = k < K ? *reinterpret_cast<const f4*>(wrow + k) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    return r;
+}
+template <int NC, class XF>
+__device__ inline float row_fma(const RowW<NC>& r, int K, int lane, XF xload) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int k = i * 256 + lane * 4;
+        if (k < K) {
+            const f4 x = xload(i, k);
+            acc += r.w[i][0] * x[0] + r.w[i][1] * x[1] + r.w[i][2] * x[2] + r.w[i][3] * x[3];
+        }
+    }
+    return acc;
+}
+
+// inputs of the dilated + cond row that live in global memory: [ring(t-2d) | ring(t-d) | (lin: LDS) | enc]
+struct GateX {
+    f4 x[AR_NCA];
+};
+__device__ inline GateX gate_x_load(const float* ring2, const float* ring1, const float* enc_t, int W, int Cd, int lane) {
+    GateX g;
+    const int K = 3 * W + Cd;
+#pragma unroll
+    for (int i = 0; i < AR_NCA; ++i) {
+        const int k = i * 256 + lane * 4;
+        const float* p = k < W ? ring2 + k : k < 2 * W ? ring1 + (k - W) : k < 3 * W ? nullptr : enc_t + (k - 3 * W);
+        g.x[i] = (k < K && p) ? *reinterpret_cast<const f4*>(p) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    return g;
+}
+
+// first kernel of a step: lin_0 = conv_start (every workgroup recomputes it: 3 MACs per channel),
+// s = skip_start(lin_0), d_0 = dilated_conv_1 + mel_cond_1 pre-activations.  Rows: [0,S) s, [S,S+G) d.
+__global__ __launch_bounds__(256) void ar_first_m_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ wav_in,
+    const float* __restrict__ forced, int Tn, const float* __restrict__ wb, const float* __restrict__ Wss,
+    const float* __restrict__ bss, const float* __restrict__ Wd, const float* __restrict__ bd,
+    const float* __restrict__ enc, int per_step, size_t ring_off, int dil) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];          // lin_0 [B][W]
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool is_s = o < D.S, is_d = !is_s && o < D.S + D.G;
+    const int r = o - D.S, K = 3 * D.W + D.Cd;
+    const float* ring = state + L.rings + (size_t)D.B * ring_off;
+    const size_t slot2 = (size_t)((t + 1) % (2 * dil + 1)) * D.B;          // lin_0[t-2d]
+    const size_t slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.B;    // lin_0[t-d]
+    RowW<AR_NCA> wd;
+    RowW<AR_NCH> ws;
+    GateX gx[AR_GEMV_MAXB];
+    float bias = 0.f;
+    if (is_d) {
+        wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
+#pragma unroll
+        for (int b = 0; b < AR_GEMV_MAXB; ++b)
+            if (b < D.B)
+                gx[b] = gate_x_load(ring + (slot2 + b) * D.W, ring + (slot1 + b) * D.W,
+                                    enc + ((size_t)b * Tn + ti) * D.Cd, D.W, D.Cd, lane);
+        bias = bd[r];
+    } else if (is_s) {
+        ws = row_load<AR_NCH>(Wss + (size_t)o * D.W, D.W, lane);
+        bias = bss[o];
+    }
+    float* ur = state + L.uring;
+    for (int i = threadIdx.x; i < D.B * D.W; i += 256) {
+        const int b = i / D.W, c = i - b * D.W;
+        float a;
+        if (wav_in) a = wav_in[b];
+        else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
+        else a = t > 0 ? state[L.a_prev + b] : 0.f;                 // fastgen.py:154: audio starts at 0
+        const float u = D.mu ? wn_mu_law_scaled(a) : a;
+        const float u1 = ur[((t + 3) & 3) * D.B + b], u2 = ur[((t + 2) & 3) * D.B + b];
+        const float v = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+        sh[i] = v;
+        if (blockIdx.x == 0) {
+            state[L.l + i] = v;                                                          // lin_0, buffer 0
+            state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + c] = v;
+            if (c == 0) ur[(t & 3) * D.B + b] = u;
+        }
+    }
+    __syncthreads();
+    if (!is_s && !is_d) return;
+#pragma unroll
+    for (int b = 0; b < AR_GEMV_MAXB; ++b) {
+        if (b >= D.B) break;
+        const float* lin = sh + (size_t)b * D.W;
+        if (is_s) {
+            const float v = wave_sum(row_fma<AR_NCH>(ws, D.W, lane, [&](int, int k) {
+                return *reinterpret_cast<const f4*>(lin + k); })) + bias;
+            if (lane == 0) state[L.s + (size_t)b * D.S + o] = v;
+        } else {
+            const float v = wave_sum(row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[b].x[i]; })) + bias;
+            if (lane == 0) state[L.dbuf + (size_t)b * D.G + r] = v;                       // d_0, buffer 0
+        }
+    }
+}
+
+// layer kernel j = 1..N (N = LAST): rows [0,W) lin_j (+ ring push), [W,W+S) s += skip_{j-1},
+// [W+S, W+S+G) d_j.  LAST: only the skip rows (lin_N and d_N do not exist).
+template <bool LAST>
+__global__ __launch_bounds__(256) void ar_layer_m_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, int cur, const float* __restrict__ Wrs,
+    const float* __restrict__ brs, const float* __restrict__ Wd, const float* __restrict__ Wcomp,
+    const float* __restrict__ bm, const float* __restrict__ enc, int Tn, int per_step, size_t ring_off, int dil) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];          // m [B][H] | lin_{j-1} [B][W]
+    const int H = D.G / 2;
+    float* shm = sh;
+    float* shl = sh + (size_t)D.B * H;
+    const long long t = ar_step_of(state);
+    const long long ti = per_step ? 0 : t;
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = LAST ? o + D.W : o;                                 // row of [res | skip | d]
+    const bool is_rs = row < D.W + D.S, is_d = !LAST && !is_rs && row < D.W + D.S + D.G;
+    const int r = row - D.W - D.S, K = 3 * D.W + D.Cd;
+    const float* ring = state + L.rings + (size_t)D.B * ring_off;
+    const size_t slot2 = (size_t)((t + 1) % (2 * dil + 1)) * D.B;
+    const size_t slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.B;
+    // all global loads of this wave's row are in flight before the gate prologue
+    RowW<AR_NCA> wd;
+    RowW<AR_NCH> wh;
+    GateX gx[AR_GEMV_MAXB];
+    float bias = 0.f;
+    if (is_d) {
+        wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
+        wh = row_load<AR_NCH>(Wcomp + (size_t)r * H, H, lane);
+#pragma unroll
+        for (int b = 0; b < AR_GEMV_MAXB; ++b)
+            if (b < D.B)
+                gx[b] = gate_x_load(ring + (slot2 + b) * D.W, ring + (slot1 + b) * D.W,
+                                    enc + ((size_t)b * Tn + ti) * D.Cd, D.W, D.Cd, lane);
+        bias = bm[r];
+    } else if (is_rs) {
+        wh = row_load<AR_NCH>(Wrs + (size_t)row * H, H, lane);
+        bias = brs[row];
+    }
+    // skip rows accumulate into s: fetch the old values with the other loads, not after the reduction
+    float sold[AR_GEMV_MAXB];
+#pragma unroll
+    for (int b = 0; b < AR_GEMV_MAXB; ++b)
+        sold[b] = (is_rs && row >= D.W && b < D.B) ? state[L.s + (size_t)b * D.S + (row - D.W)] : 0.f;
+    const float* dprev = state + L.dbuf + (size_t)cur * D.B * D.G;
+    const float* lprev = state + (cur ? L.l2 : L.l);
+    // gate of the previous layer (wavenet.py:479), recomputed by every workgroup
+    for (int i = threadIdx.x; i < D.B * H; i += 256) {
+        const int b = i / H, k = i - b * H;
+        shm[i] = ar_gate(dprev[(size_t)b * D.G + k], dprev[(size_t)b * D.G + H + k]);
+    }
+    if (!LAST)
+        for (int i = threadIdx.x; i < D.B * D.W; i += 256) shl[i] = lprev[i];
+    __syncthreads();
+    if (!is_rs && !is_d) return;
+    const int nxt = cur ^ 1;
+#pragma unroll
+    for (int b = 0; b < AR_GEMV_MAXB; ++b) {
+        if (b >= D.B) break;
+        const float* m = shm + (size_t)b * H;
+        const float* lin = shl + (size_t)b * D.W;
+        if (is_rs) {
+            const float v = wave_sum(row_fma<AR_NCH>(wh, H, lane, [&](int, int k) {
+                return *reinterpret_cast<const f4*>(m + k); })) + bias;
+            if (lane == 0) {
+                if (row < D.W) {
+                    const float ln = lin[row] + v;                                        // wavenet.py:481-485
+                    state[(nxt ? L.l2 : L.l) + (size_t)b * D.W + row] = ln;
+                    // lin_j is the INPUT of layer j: its queue slot of this step (masked.py:357-359)
+                    state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + row] = ln;
+                } else {
+                    state[L.s + (size_t)b * D.S + (row - D.W)] = sold[b] + v;             // wavenet.py:486-490
+                }
+            }
+        } else {
+            float acc = row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[b].x[i]; });
+            acc += row_fma<AR_NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
+            const float v = wave_sum(acc) + bias;
+            if (lane == 0) state[L.dbuf + (size_t)nxt * D.B * D.G + (size_t)b * D.G + r] = v;
+        }
+    }
+}
+
+// Wcomp[o][k] = sum_c Wd[o][2W + c] * Wres[c][k]   (run once at wn_finalize; fp64 accumulation)
+__global__ void ar_compose_kernel(const float* __restrict__ Wd, const float* __restrict__ Wrs,
+                                  float* __restrict__ Wcomp, int G, int W, int H, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+    if (k >= H || o >= G) return;
+    double acc = 0.0;
+    for (int c = 0; c < W; ++c) acc += (double)Wd[(size_t)o * K + 2 * W + c] * (double)Wrs[(size_t)c * H + k];
+    Wcomp[(size_t)o * H + k] = (float)acc;
 }
 
 // ---- sampling heads (loss_func.py:140-206) + feedback de-quantisation (fastgen.py:163-167) ----
@@ -593,6 +836,35 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
     if (L.NB) return ar_enqueue_step_b<4>(h, state, L, D, wav_in, forced, enc, Tn, per_step, rnd, seed, idx, wav, out_params, st);
     const ArPack& P = h->ar;
     const float* blob = h->d_blob;
+    if (B <= AR_GEMV_MAXB && P.layers.size() >= 1 && 3 * D.W + D.Cd <= 256 * AR_NCA && D.G / 2 <= 256 * AR_NCH &&
+        D.W <= 256 * AR_NCH) {
+        // merged step: one launch per layer (see ar_layer_m_kernel)
+        const size_t n = P.layers.size();
+        const ArLayerPack& l0 = P.layers[0];
+        hipLaunchKernelGGL(ar_first_m_kernel, dim3((D.S + D.G + 3) / 4), dim3(256), (size_t)B * D.W * sizeof(float), st,
+                           state, L, D, wav_in, forced, Tn, blob + P.start_off, blob + P.wss_off, blob + P.bss_off,
+                           blob + l0.wd_off, blob + l0.bd_off, enc, per_step, l0.ring_off, l0.dilation);
+        const size_t shb = (size_t)B * (D.G / 2 + D.W) * sizeof(float);
+        for (size_t j = 1; j < n; ++j) {
+            const ArLayerPack& lp = P.layers[j];
+            const ArLayerPack& pv = P.layers[j - 1];
+            hipLaunchKernelGGL(ar_layer_m_kernel<false>, dim3((D.W + D.S + D.G + 3) / 4), dim3(256), shb, st, state, L, D,
+                               (int)((j - 1) & 1), blob + pv.wrs_off, blob + pv.brs_off, blob + lp.wd_off,
+                               blob + lp.wcomp_off, blob + lp.bm_off, enc, Tn, per_step, lp.ring_off, lp.dilation);
+        }
+        const ArLayerPack& pl = P.layers[n - 1];
+        hipLaunchKernelGGL(ar_layer_m_kernel<true>, dim3((D.S + 3) / 4), dim3(256), shb, st, state, L, D,
+                           (int)((n - 1) & 1), blob + pl.wrs_off, blob + pl.brs_off, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, enc, Tn, per_step, (size_t)0, 1);
+        hipLaunchKernelGGL(ar_rows_kernel<2>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo1_off,
+                           blob + P.bo1_off, D.S, D.S + D.Cd, enc, Tn, per_step, (size_t)0, 1);
+        hipLaunchKernelGGL(ar_rows_kernel<3>, dim3((D.OW + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo2_off,
+                           blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step, (size_t)0, 1);
+        hipLaunchKernelGGL(ar_sample_kernel, dim3(B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
+                           per_step, Tn, idx, wav, out_params);
+        hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
+        return;
+    }
     hipLaunchKernelGGL(ar_start_kernel, dim3((B * D.W + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
                        forced, Tn, blob + P.start_off);
     hipLaunchKernelGGL(ar_rows_kernel<0>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wss_off,
@@ -671,7 +943,7 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
         ArLayerPack lp;
         lp.dilation = 1 << (i % c.num_stages);                                     // wavenet.py:453
         lp.ring_off = ring;
-        ring += (size_t)2 * lp.dilation * W;
+        ring += (size_t)(2 * lp.dilation + 1) * W;      // 2d+1 slots: the merged step reads t-2d while t is pushed
         const int K = 3 * W + Cd;
         std::vector<float> Wd = wn_get_kernel(h, "dilated_conv_" + s, "W", false);   // [3][W][G]
         lp.wd_off = begin();
@@ -699,6 +971,21 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
             const auto& bs = var("skip_" + s + "/biases");
             blob.insert(blob.end(), br.begin(), br.end());
             blob.insert(blob.end(), bs.begin(), bs.end());
+        }
+        // merged-step additions: space for the composite matrix (filled on the device by
+        // wn_ar_post_upload) and the composite bias bm = bd + Wd[tap t] . bres_{j-1}
+        if (i > 0) {
+            const ArLayerPack& pv = P.layers.back();
+            lp.wcomp_off = begin();
+            blob.resize(blob.size() + (size_t)G * (G / 2));
+            lp.bm_off = begin();
+            blob.resize(blob.size() + G);
+            for (int o = 0; o < G; ++o) {
+                double acc = blob[lp.bd_off + o];
+                for (int cc = 0; cc < W; ++cc)
+                    acc += (double)blob[lp.wd_off + (size_t)o * K + 2 * W + cc] * (double)blob[pv.brs_off + cc];
+                blob[lp.bm_off + o] = (float)acc;
+            }
         }
         P.layers.push_back(lp);
     }
@@ -752,6 +1039,20 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
         P.wo1_b_off = frag(P.wo1_off, S, S + Cd);
         P.wo2_b_off = frag(P.wo2_off, OW, S);
     }
+    return WN_OK;
+}
+
+int wn_ar_post_upload(wn_handle* h) {
+    const wn_config& c = h->cfg;
+    const int W = c.width, G = c.gate_width, H = G / 2, K = 3 * W + c.deconv_width;
+    for (size_t j = 1; j < h->ar.layers.size(); ++j) {
+        const ArLayerPack& lp = h->ar.layers[j];
+        const ArLayerPack& pv = h->ar.layers[j - 1];
+        hipLaunchKernelGGL(ar_compose_kernel, dim3((H + 255) / 256, G), dim3(256), 0, 0, h->d_blob + lp.wd_off,
+                           h->d_blob + pv.wrs_off, h->d_blob + lp.wcomp_off, G, W, H, K);
+    }
+    WN_HIP(h, hipDeviceSynchronize());
+    WN_HIP(h, hipGetLastError());
     return WN_OK;
 }
 

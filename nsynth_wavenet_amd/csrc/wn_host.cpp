@@ -245,6 +245,10 @@ extern "C" int wn_finalize(wn_handle* h) {
     h->blob_floats = blob.size();
     WN_HIP(h, hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float)));
     WN_HIP(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (h->cfg.kind == WN_KIND_TEACHER) {
+        rc = wn_ar_post_upload(h);
+        if (rc) return rc;
+    }
     // host copies are no longer needed
     for (auto& kv : h->vars) std::vector<float>().swap(kv.second.data);
     h->finalized = true;

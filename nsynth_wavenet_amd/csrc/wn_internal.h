@@ -60,6 +60,9 @@ struct ArLayerPack {
     size_t brs_off;   // [width + skip]
     size_t wd_b_off, wrs_b_off;   // the same matrices in MFMA A-fragment order (batched step)
     size_t brs_gate_off;          // [res | skip | gate] biases for the batched res/skip kernel
+    // merged GEMV step: d_j = wd_j.[ring(t-2d) | ring(t-d) | lin_{j-1} | enc] + wcomp_j.m_{j-1} + bm_j with
+    // wcomp_j = Wd_j[tap t] . Wres_{j-1} (computed on the device after the upload), bm_j = bd_j + Wd_j[tap t].bres_{j-1}
+    size_t wcomp_off = 0, bm_off = 0;
     int dilation;
     size_t ring_off;  // float offset of this layer's ring inside the state (per batch elem)
 };
@@ -185,5 +188,6 @@ std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, c
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);
 void wn_ar_release(wn_handle* h);
+int wn_ar_post_upload(wn_handle* h);   // device-side part of the AR packing (composite matrices)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
