@@ -589,8 +589,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     const wn_config& c = h->cfg;
 
     const bool f16x3 = c.precision == WN_PREC_F16X3;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!h->iaf_attrs_set) {       // per handle: function attributes belong to the handle's device
         int rc = wn_iaf_h_set_attrs(h);
         if (rc) return rc;
         rc = wn_iaf_c_set_attrs(h);
@@ -601,7 +600,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_HEAD_FLOATS * sizeof(float)));
-        attr_done = true;
+        h->iaf_attrs_set = true;
     }
 
     // zero left pads

@@ -96,6 +96,7 @@ struct wn_handle {
     wn_config cfg;
     std::map<std::string, HostTensor> vars;   // expected variables (+ data once set)
     bool finalized = false;
+    bool iaf_attrs_set = false;               // dynamic-LDS limits of the IAF kernels raised on this device
     int device = 0;
     float* d_blob = nullptr;
     size_t blob_floats = 0;
