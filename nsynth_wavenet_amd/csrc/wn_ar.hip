@@ -17,7 +17,7 @@
 //    current-tap term, so a layer is a single dependent phase) -- 35 launches per step;
 //  * B >= 4: the batch is the N dimension of v_mfma_f32_16x16x4_f32 (activations
 //    [feature][padded batch]), so one pass over the 119 MB of weights serves every utterance
-//    (three launches per layer, ~95 per step).
+//    (two launches per layer, 66 per step).
 // Both are chains of dependent, launch-latency-bound kernels.
 #include <cstdlib>
 #include <cstring>
@@ -70,9 +70,9 @@ ArStateLayout ar_state_layout(const wn_handle* h, int B) {
     L.ebuf = carve((size_t)B * c.out_width);
     L.encT = carve(Bp * c.deconv_width);
     // K-split partial pre-activations of the gate GEMM: [ceil(K/256)][gate_width][NB]
-    L.slab = carve(L.NB ? (size_t)((3 * c.width + c.deconv_width + 255) / 256) * c.gate_width * Bp : 0);
+    L.slab = carve(L.NB ? (size_t)((3 * c.width + c.deconv_width + c.gate_width / 2 + 255) / 256) * c.gate_width * Bp : 0);
     // merged GEMV step: second residual-stream buffer and two pre-activation buffers (ping-pong per layer)
-    L.l2 = carve(L.NB ? 0 : (size_t)B * c.width);
+    L.l2 = carve(Bp * c.width);
     L.dbuf = carve(L.NB ? 0 : 2 * (size_t)B * c.gate_width);
     L.total = o;
     return L;
@@ -114,7 +114,7 @@ __global__ void ar_start_kernel(float* __restrict__ state, ArStateLayout L, ArDi
 // plain `for k` loop waits one L2/Infinity-Cache round trip per iteration, which at batch 1
 // was most of the step time.  Weights are held in registers across the batch loop.
 constexpr int AR_KC = 4;
-constexpr int AR_MAXSLAB = 8;       // K-split slabs of the batched gate GEMM (K <= 2048)                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
+constexpr int AR_MAXSLAB = 12;      // K-split slabs of the batched gate GEMM (K = 3W + Cd + G/2 <= 3072)                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
 
 // ---- generic row GEMV: y[b][o] (op)= bias[o] + W[o][:] . x[b][:]  (masked.py:383-405) ----
 // MODE 0: skip_start  s  = .            x = l
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
 
 __global__ void ar_start_b_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
                                   const float* __restrict__ wav_in, const float* __restrict__ forced,
-                                  const float* __restrict__ enc, int Tn, int per_step, const float* __restrict__ wb) {
+                                  const float* __restrict__ enc, int Tn, int per_step, const float* __restrict__ wb,
+                                  size_t ring_off, int dil) {
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
     const int NB = L.NB;
@@ -621,17 +622,18 @@ __global__ void ar_start_b_kernel(float* __restrict__ state, ArStateLayout L, Ar
             u1 = ur[((t + 3) & 3) * D.B + b];
             u2 = ur[((t + 2) & 3) * D.B + b];
         }
-        state[L.l + (size_t)c * NB + b] = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+        const float v = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+        state[L.l + (size_t)c * NB + b] = v;
+        // lin_0 is the input of the first causal layer: its queue slot of this step (masked.py:357-359)
+        state[L.rings + ring_off * NB + ((size_t)(t % (2 * dil + 1)) * D.W + c) * NB + b] = v;
         if (c == 0 && b < D.B) ur[(t & 3) * D.B + b] = u;
     }
 }
 
-// MODE 0 skip_start: s = W l            MODE 1 res/skip: l += W g (rows < W, + ring push), s += W g
-// MODE 2 out1: z = relu(W [relu(s)|enc]) MODE 3 out2: out = W z
-// MODE 4 gate pre-activations: K is split over blockIdx.z (256 inputs per workgroup, so that all
-//        256 CUs stream weights) and each workgroup writes its partial sums as a slab
-//        [kz][row][NB]; x = [ring[t-2d] | ring[t-d] | l | enc].  ar_gate_fin_b_kernel sums the
-//        slabs in a fixed order, adds the bias and applies sigmoid * tanh.
+// The batched step is a chain of GEMMs [rows][K] x [K][NB]:
+//   ar_layer_b_kernel   the res/skip GEMM of layer j-1 and the K-split pre-activation slabs of layer j
+//   ar_gate_fin_b_kernel sums the slabs in a fixed order, adds the bias and applies sigmoid * tanh
+//   ar_gemm_b_kernel    MODE 2 out1: z = relu(W [relu(s)|enc]);  MODE 3 out2: out = W z
 // g[k][b] = sigmoid(bias[k] + sum_z slab[z][k][b]) * tanh(bias[m+k] + sum_z slab[z][m+k][b])  (wavenet.py:479)
 __global__ void ar_gate_fin_b_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
                                      const float* __restrict__ bias, int nslab) {
@@ -674,7 +676,7 @@ __device__ inline VecNT<NT> load_nt(const float* p) {
 template <int MODE, int NT>
 __global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Ap,
-    const float* __restrict__ bias, int rows, int K, size_t ring_off, int dil) {
+    const float* __restrict__ bias, int rows, int K) {
     constexpr int NRB = 1;
     extern __shared__ __attribute__((aligned(16))) f4 red[];      // [waves][NT][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -682,25 +684,13 @@ __global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
     const int NB = L.NB;
     const int mb = blockIdx.x;
     const int col0 = blockIdx.y * 16 * NT + NT * n;
-    const long long t = ar_step_of(state);
     const int nks4 = K / 16;
-    // MODE 4: this workgroup owns k-groups [16*z, 16*z+16); otherwise all of K
-    const int g0 = MODE == 4 ? 16 * blockIdx.z : 0, g1 = MODE == 4 ? min(nks4, g0 + 16) : nks4;
-    const int per = (g1 - g0 + nw - 1) / nw;
-    const int k4a = g0 + wave * per, k4b = min(g1, k4a + per);
-
-    const float* ring = state + L.rings + ring_off * NB;
-    const size_t slot2 = (size_t)(t % (2 * dil)) * D.W, slot1 = (size_t)((t + dil) % (2 * dil)) * D.W;
+    const int per = (nks4 + nw - 1) / nw;
+    const int k4a = wave * per, k4b = min(nks4, k4a + per);
     // row pointer of input feature k (a k-group of 16 never straddles two sources)
     auto xrow = [&](int k) -> const float* {
-        if (MODE == 0) return state + L.l + (size_t)k * NB;
-        if (MODE == 1) return state + L.g + (size_t)k * NB;
         if (MODE == 2) return k < D.S ? state + L.s + (size_t)k * NB : state + L.encT + (size_t)(k - D.S) * NB;
-        if (MODE == 3) return state + L.z + (size_t)k * NB;
-        if (k < D.W) return ring + (slot2 + k) * NB;
-        if (k < 2 * D.W) return ring + (slot1 + (k - D.W)) * NB;
-        if (k < 3 * D.W) return state + L.l + (size_t)(k - 2 * D.W) * NB;
-        return state + L.encT + (size_t)(k - 3 * D.W) * NB;
+        return state + L.z + (size_t)k * NB;
     };
     f4 acc[NRB][NT];
 #pragma unroll
@@ -708,7 +698,6 @@ __global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
 #pragma unroll
         for (int e = 0; e < NT; ++e) acc[rb][e] = (f4){0.f, 0.f, 0.f, 0.f};
     const f4* A0 = reinterpret_cast<const f4*>(Ap) + (size_t)mb * nks4 * 64 + lane;
-#pragma unroll 4
     for (int k4 = k4a; k4 < k4b; ++k4) {
         f4 a[NRB];
         a[0] = A0[(size_t)k4 * 64];
@@ -750,26 +739,110 @@ __global__ __launch_bounds__(1024) void ar_gemm_b_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mb + 4 * q + r;
-            if (MODE == 4) {
-                state[L.slab + ((size_t)blockIdx.z * D.G + row) * NB + col] = v[0][r];
-            } else if (row < rows) {
+            if (row < rows) {
                 const float val = v[0][r] + bias[row];
-                if (MODE == 0) state[L.s + (size_t)row * NB + col] = val;
-                else if (MODE == 1) {
-                    if (row < D.W) {
-                        float* lp = state + L.l + (size_t)row * NB + col;
-                        const float lold = *lp;
-                        // push the layer INPUT into slot t mod 2d (masked.py:357-359)
-                        state[L.rings + ring_off * NB + ((size_t)(t % (2 * dil)) * D.W + row) * NB + col] = lold;
-                        *lp = lold + val;
-                    } else {
-                        state[L.s + (size_t)(row - D.W) * NB + col] += val;
-                    }
-                } else if (MODE == 2) state[L.z + (size_t)row * NB + col] = fmaxf(val, 0.f);   // wavenet.py:499
+                if (MODE == 2) state[L.z + (size_t)row * NB + col] = fmaxf(val, 0.f);   // wavenet.py:499
                 else state[L.out + (size_t)row * NB + col] = val;
             }
         }
     }
+}
+
+// ---- merged batched layer kernel: the res/skip GEMM of layer j-1 and the K-split pre-activation
+// slabs of layer j in ONE launch (both depend only on m_{j-1} and lin_{j-1}; see ar_layer_m_kernel
+// for the algebra).  blockIdx.x < rs_blocks: 16 rows of [res | skip] (FIRST: skip_start), all of K;
+// otherwise (row block, K slab) of [wd_j | wcomp_j] . [ring(t-2d) | ring(t-d) | lin_{j-1} | enc | m_{j-1}].
+template <int NT, bool FIRST>
+__global__ __launch_bounds__(256) void ar_layer_b_kernel(
+    float* __restrict__ state, ArStateLayout L, ArDims D, int cur, const float* __restrict__ Ars,
+    const float* __restrict__ brs, int rs_rows, int rs_K, const float* __restrict__ Adc, int Kd, int nslab,
+    size_t ring_off, int dil) {
+    extern __shared__ __attribute__((aligned(16))) f4 red[];      // [4 waves][NT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int NB = L.NB;
+    const int rs_blocks = (rs_rows + 15) / 16;
+    const bool is_rs = (int)blockIdx.x < rs_blocks;
+    const int task = is_rs ? blockIdx.x : blockIdx.x - rs_blocks;
+    const int mb = is_rs ? task : task / nslab, z = is_rs ? 0 : task - mb * nslab;
+    const int col0 = blockIdx.y * 16 * NT + NT * n;
+    const long long t = ar_step_of(state);
+    const int K = is_rs ? rs_K : Kd, nks4 = K / 16;
+    const int g0 = is_rs ? 0 : 16 * z, g1 = is_rs ? nks4 : min(nks4, g0 + 16);
+    const int per = (g1 - g0 + 3) / 4;
+    const int k4a = g0 + wave * per, k4b = min(g1, k4a + per);
+    const float* lcur = state + (cur ? L.l2 : L.l);
+    float* lnxt = state + (cur ? L.l : L.l2);
+    const float* ring = state + L.rings + ring_off * NB;
+    const size_t slot2 = (size_t)((t + 1) % (2 * dil + 1)) * D.W, slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.W;
+    auto xrow = [&](int k) -> const float* {
+        if (is_rs) return (FIRST ? lcur : state + L.g) + (size_t)k * NB;
+        if (k < D.W) return ring + (slot2 + k) * NB;
+        if (k < 2 * D.W) return ring + (slot1 + (k - D.W)) * NB;
+        if (k < 3 * D.W) return lcur + (size_t)(k - 2 * D.W) * NB;
+        if (k < 3 * D.W + D.Cd) return state + L.encT + (size_t)(k - 3 * D.W) * NB;
+        return state + L.g + (size_t)(k - 3 * D.W - D.Cd) * NB;
+    };
+    f4 acc[NT];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) acc[e] = (f4){0.f, 0.f, 0.f, 0.f};
+    const f4* A0 = reinterpret_cast<const f4*>(is_rs ? Ars : Adc) + (size_t)mb * nks4 * 64 + lane;
+    for (int k4 = k4a; k4 < k4b; ++k4) {
+        const f4 a = A0[(size_t)k4 * 64];
+        float bv[4][NT];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const VecNT<NT> xv = load_nt<NT>(xrow(16 * k4 + 4 * jj + q) + col0);
+#pragma unroll
+            for (int e = 0; e < NT; ++e) bv[jj][e] = xv.v[e];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int e = 0; e < NT; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], bv[jj][e], acc[e], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < NT; ++e) red[(wave * NT + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+        f4 v = red[e * 64 + lane];
+        for (int w = 1; w < 4; ++w) v += red[(w * NT + e) * 64 + lane];                  // fixed order
+        const int col = col0 + e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mb + 4 * q + r;
+            if (!is_rs) {
+                state[L.slab + ((size_t)z * D.G + row) * NB + col] = v[r];
+            } else if (row < rs_rows) {
+                const float val = v[r] + brs[row];
+                if (FIRST) state[L.s + (size_t)row * NB + col] = val;
+                else if (row < D.W) {
+                    const float ln = lcur[(size_t)row * NB + col] + val;
+                    lnxt[(size_t)row * NB + col] = ln;
+                    if (Adc)   // lin_j feeds layer j: its queue slot of this step (masked.py:357-359)
+                        state[L.rings + ring_off * NB + ((size_t)(t % (2 * dil + 1)) * D.W + row) * NB + col] = ln;
+                } else {
+                    state[L.s + (size_t)(row - D.W) * NB + col] += val;
+                }
+            }
+        }
+    }
+}
+
+// A-fragment order of [wd | wcomp] (rows G, K = KA + H), built on the device after the composite
+__global__ void ar_frag_dc_kernel(const float* __restrict__ wd, const float* __restrict__ wcomp,
+                                  float* __restrict__ dst, int G, int KA, int H) {
+    const int nks4 = (KA + H) / 16;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(G / 16) * nks4 * 256;
+    if (i >= total) return;
+    const int jj = i & 3, lane = (i >> 2) & 63;
+    const size_t blk = i >> 8;
+    const int k4 = blk % nks4, mb = blk / nks4;
+    const int row = 16 * mb + (lane & 15), k = 16 * k4 + 4 * jj + (lane >> 4);
+    dst[i] = k < KA ? wd[(size_t)row * KA + k] : wcomp[(size_t)row * H + (k - KA)];
 }
 
 __global__ void ar_advance_kernel(float* state) {
@@ -803,24 +876,44 @@ void ar_enqueue_step_b(wn_handle* h, float* state, const ArStateLayout& L, const
         return w > cap ? cap : (w < 1 ? 1 : w);
     };
     auto lds = [&](int w, int nrb) { return (size_t)w * nrb * NT * 1024; };
-    const int w1 = nwaves(D.G / 2, 1), w0 = nwaves(D.W, 1), w2 = nwaves(D.S + D.Cd, 1), w3 = nwaves(D.S, 1);
-    const int nslab = (3 * D.W + D.Cd + 255) / 256;
+    const int w2 = nwaves(D.S + D.Cd, 1), w3 = nwaves(D.S, 1);
+    const size_t n = P.layers.size();
+    const int KA = 3 * D.W + D.Cd, H = D.G / 2;
+    const ArLayerPack& l0 = P.layers[0];
     hipLaunchKernelGGL(ar_start_b_kernel, dim3((rows * NB + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
-                       forced, enc, Tn, per_step, blob + P.start_off);
-    hipLaunchKernelGGL((ar_gemm_b_kernel<0, NT>), dim3(D.S / 16, chunks), dim3(64 * w0), lds(w0, 1), st, state, L, D,
-                       blob + P.wss_b_off, blob + P.bss_off, D.S, D.W, (size_t)0, 1);
-    for (const ArLayerPack& lp : P.layers) {
-        hipLaunchKernelGGL((ar_gemm_b_kernel<4, NT>), dim3(D.G / 16, chunks, nslab), dim3(256), lds(4, 1), st, state, L, D,
-                           blob + lp.wd_b_off, blob + lp.bd_off, D.G, 3 * D.W + D.Cd, lp.ring_off, lp.dilation);
-        hipLaunchKernelGGL(ar_gate_fin_b_kernel, dim3((D.G / 2 * NB + 255) / 256), dim3(256), 0, st, state, L, D,
-                           blob + lp.bd_off, nslab);
-        hipLaunchKernelGGL((ar_gemm_b_kernel<1, NT>), dim3((D.W + D.S) / 16, chunks), dim3(64 * w1), lds(w1, 1), st, state, L, D,
-                           blob + lp.wrs_b_off, blob + lp.brs_off, D.W + D.S, D.G / 2, lp.ring_off, lp.dilation);
+                       forced, enc, Tn, per_step, blob + P.start_off, l0.ring_off, l0.dilation);
+    // layer kernels: [res/skip of layer j-1 | pre-activation slabs of layer j] in one launch, then the
+    // slab sum + gate; lin ping-pongs between the two residual buffers (buffer 0 holds lin_0)
+    {
+        const int nslab = (KA + 255) / 256;
+        hipLaunchKernelGGL((ar_layer_b_kernel<NT, true>), dim3(D.S / 16 + D.G / 16 * nslab, chunks), dim3(256), lds(4, 1), st,
+                           state, L, D, 0, blob + P.wss_b_off, blob + P.bss_off, D.S, D.W, blob + l0.wd_b_off, KA, nslab,
+                           l0.ring_off, l0.dilation);
+        hipLaunchKernelGGL(ar_gate_fin_b_kernel, dim3((H * NB + 255) / 256), dim3(256), 0, st, state, L, D,
+                           blob + l0.bd_off, nslab);
+    }
+    for (size_t j = 1; j <= n; ++j) {
+        const ArLayerPack& pv = P.layers[j - 1];
+        const int cur = (int)((j - 1) & 1);
+        if (j < n) {
+            const ArLayerPack& lp = P.layers[j];
+            const int Kd = KA + H, nslab = (Kd + 255) / 256;
+            hipLaunchKernelGGL((ar_layer_b_kernel<NT, false>), dim3((D.W + D.S) / 16 + D.G / 16 * nslab, chunks), dim3(256),
+                               lds(4, 1), st, state, L, D, cur, blob + pv.wrs_b_off, blob + pv.brs_off, D.W + D.S, H,
+                               blob + lp.wdc_b_off, Kd, nslab, lp.ring_off, lp.dilation);
+            hipLaunchKernelGGL(ar_gate_fin_b_kernel, dim3((H * NB + 255) / 256), dim3(256), 0, st, state, L, D,
+                               blob + lp.bm_off, nslab);
+        } else {
+            // after the last layer only the skip sum is consumed
+            hipLaunchKernelGGL((ar_layer_b_kernel<NT, false>), dim3((D.W + D.S) / 16, chunks), dim3(256), lds(4, 1), st,
+                               state, L, D, cur, blob + pv.wrs_b_off, blob + pv.brs_off, D.W + D.S, H,
+                               (const float*)nullptr, 0, 1, (size_t)0, 1);
+        }
     }
     hipLaunchKernelGGL((ar_gemm_b_kernel<2, NT>), dim3(D.S / 16, chunks), dim3(64 * w2), lds(w2, 1), st, state, L, D,
-                       blob + P.wo1_b_off, blob + P.bo1_off, D.S, D.S + D.Cd, (size_t)0, 1);
+                       blob + P.wo1_b_off, blob + P.bo1_off, D.S, D.S + D.Cd);
     hipLaunchKernelGGL((ar_gemm_b_kernel<3, NT>), dim3((D.OW + 15) / 16, chunks), dim3(64 * w3), lds(w3, 1), st, state, L, D,
-                       blob + P.wo2_b_off, blob + P.bo2_off, D.OW, D.S, (size_t)0, 1);
+                       blob + P.wo2_b_off, blob + P.bo2_off, D.OW, D.S);
     hipLaunchKernelGGL(ar_sample_kernel, dim3(D.B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
                        per_step, Tn, idx, wav, out_params);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
@@ -1026,10 +1119,16 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
         return off;
     };
     P.wss_b_off = 0;
-    if (K_ok(W) && K_ok(Cd) && K_ok(S) && K_ok(G / 2) && (3 * W + Cd + 255) / 256 <= AR_MAXSLAB) {
+    if (K_ok(W) && K_ok(Cd) && K_ok(S) && K_ok(G / 2) && (3 * W + Cd + G / 2 + 255) / 256 <= AR_MAXSLAB) {
         P.wss_b_off = frag(P.wss_off, S, W);
-        for (ArLayerPack& lp : P.layers) {
-            lp.wd_b_off = frag(lp.wd_off, G, 3 * W + Cd);
+        for (size_t li = 0; li < P.layers.size(); ++li) {
+            ArLayerPack& lp = P.layers[li];
+            if (li == 0) {
+                lp.wd_b_off = frag(lp.wd_off, G, 3 * W + Cd);
+            } else {                         // [wd | wcomp] fragments are written on the device (wn_ar_post_upload)
+                lp.wdc_b_off = begin();
+                blob.resize(blob.size() + (size_t)G * (3 * W + Cd + G / 2));
+            }
             lp.wrs_b_off = frag(lp.wrs_off, W + S, G / 2);
             // bias vector of the batched res/skip kernel: [res | skip | gate (dilated + cond)]
             lp.brs_gate_off = begin();
@@ -1050,6 +1149,11 @@ int wn_ar_post_upload(wn_handle* h) {
         const ArLayerPack& pv = h->ar.layers[j - 1];
         hipLaunchKernelGGL(ar_compose_kernel, dim3((H + 255) / 256, G), dim3(256), 0, 0, h->d_blob + lp.wd_off,
                            h->d_blob + pv.wrs_off, h->d_blob + lp.wcomp_off, G, W, H, K);
+        if (lp.wdc_b_off) {
+            const size_t total = (size_t)G * (K + H);
+            hipLaunchKernelGGL(ar_frag_dc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0,
+                               h->d_blob + lp.wd_off, h->d_blob + lp.wcomp_off, h->d_blob + lp.wdc_b_off, G, K, H);
+        }
     }
     WN_HIP(h, hipDeviceSynchronize());
     WN_HIP(h, hipGetLastError());

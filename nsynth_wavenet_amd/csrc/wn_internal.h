@@ -63,6 +63,7 @@ struct ArLayerPack {
     // merged GEMV step: d_j = wd_j.[ring(t-2d) | ring(t-d) | lin_{j-1} | enc] + wcomp_j.m_{j-1} + bm_j with
     // wcomp_j = Wd_j[tap t] . Wres_{j-1} (computed on the device after the upload), bm_j = bd_j + Wd_j[tap t].bres_{j-1}
     size_t wcomp_off = 0, bm_off = 0;
+    size_t wdc_b_off = 0;         // A-fragment order of [wd_j | wcomp_j] for the batched merged step (built on the device)
     int dilation;
     size_t ring_off;  // float offset of this layer's ring inside the state (per batch elem)
 };
