@@ -88,27 +88,6 @@ __device__ inline long long ar_step_of(const float* state) {
     return *reinterpret_cast<const long long*>(state);
 }
 
-// ---- conv_start (wavenet.py:426-434): l = b + W0 u[t-2] + W1 u[t-1] + W2 u[t] ----
-// u[t] = encoded network input of step t = previous audio sample (fastgen.py:153-168)
-__global__ void ar_start_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
-                                const float* __restrict__ wav_in, const float* __restrict__ forced,
-                                int Tn, const float* __restrict__ wb) {
-    const long long t = ar_step_of(state);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D.B * D.W) return;
-    const int b = i / D.W, c = i - b * D.W;
-    float a;
-    if (wav_in) a = wav_in[b];                                  // wn_ar_step: explicit input
-    else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
-    else a = t > 0 ? state[L.a_prev + b] : 0.f;                 // fastgen.py:154: audio starts at 0
-    const float u = D.mu ? wn_mu_law_scaled(a) : a;
-    float* ur = state + L.uring;
-    const float u1 = ur[((t + 3) & 3) * D.B + b];               // u[t-1]
-    const float u2 = ur[((t + 2) & 3) * D.B + b];               // u[t-2]
-    state[L.l + (size_t)b * D.W + c] = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
-    if (c == 0) ur[(t & 3) * D.B + b] = u;
-}
-
 // Per-lane slice of a GEMV row: K is walked in chunks of AR_KC f4 per lane, and inside a
 // chunk EVERY load (weights, then the batch's inputs) is issued before the first use -- a
 // plain `for k` loop waits one L2/Infinity-Cache round trip per iteration, which at batch 1
@@ -117,15 +96,12 @@ constexpr int AR_KC = 4;
 constexpr int AR_MAXSLAB = 12;      // K-split slabs of the batched gate GEMM (K = 3W + Cd + G/2 <= 3072)                          // f4 per lane per chunk: 8 * 256 lanes-floats = 2048 floats of K
 
 // ---- generic row GEMV: y[b][o] (op)= bias[o] + W[o][:] . x[b][:]  (masked.py:383-405) ----
-// MODE 0: skip_start  s  = .            x = l
-// MODE 1: res/skip    l += . (o<W) and ring push of the old l; s += . (o>=W)   x = g
 // MODE 2: out1        z  = relu(.)      x = [relu(s) | enc_t]
 // MODE 3: out2        out = .           x = z
 template <int MODE>
 __global__ __launch_bounds__(256) void ar_rows_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Wm,
-    const float* __restrict__ bias, int rows, int K, const float* __restrict__ enc, int Tn, int per_step,
-    size_t ring_off, int dil) {
+    const float* __restrict__ bias, int rows, int K, const float* __restrict__ enc, int Tn, int per_step) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= rows) return;
@@ -134,8 +110,6 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
     const float* wrow = Wm + (size_t)o * K;
     const float bo = bias[o];
     auto xptr = [&](int b, int k) -> const float* {
-        if (MODE == 0) return state + L.l + (size_t)b * D.W + k;
-        if (MODE == 1) return state + L.g + (size_t)b * (D.G / 2) + k;
         if (MODE == 2) return k < D.S ? state + L.s + (size_t)b * D.S + k
                                       : enc + ((size_t)b * Tn + ti) * D.Cd + (k - D.S);
         return state + L.z + (size_t)b * D.S + k;
@@ -176,97 +150,14 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
             if (b >= D.B) break;
             const float v = wave_sum(acc[e]) + bo;
             if (lane == 0) {
-                if (MODE == 0) state[L.s + (size_t)b * D.S + o] = v;
-                else if (MODE == 1) {
-                    if (o < D.W) {
-                        float* lp = state + L.l + (size_t)b * D.W + o;
-                        const float lold = *lp;
-                        // push the layer INPUT into slot t mod 2d (masked.py:357-359)
-                        state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil)) * D.B + b) * D.W + o] = lold;
-                        *lp = lold + v;
-                    } else {
-                        state[L.s + (size_t)b * D.S + (o - D.W)] += v;
-                    }
-                } else if (MODE == 2) state[L.z + (size_t)b * D.S + o] = fmaxf(v, 0.f);   // wavenet.py:499
+                if (MODE == 2) state[L.z + (size_t)b * D.S + o] = fmaxf(v, 0.f);   // wavenet.py:499
                 else state[L.out + (size_t)b * D.OW + o] = v;
             }
         }
     }
 }
 
-// ---- dilated causal_linear + conditioning + gate (wavenet.py:456-479, masked.py:369-376) ----
-// one WORKGROUP = gate pair (o, o+m); its four waves split K = 3W + Cd in quarters (at batch 1
-// the kernel is one memory round trip long, so the only lever is more, smaller waves), partial
-// sums meet in LDS.  x = [ring[t-2d] | ring[t-d] | l | enc_t]
-__global__ __launch_bounds__(256) void ar_gate_kernel(
-    float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ Wm,
-    const float* __restrict__ bias, const float* __restrict__ enc, int Tn, int per_step, size_t ring_off,
-    int dil) {
-    __shared__ float part[4][AR_BT][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = D.G / 2;
-    const int o = blockIdx.x;
-    const long long t = ar_step_of(state);
-    const long long ti = per_step ? 0 : t;
-    const int K = 3 * D.W + D.Cd, KQ = K / 4;
-    const int k0 = wave * KQ, k1 = k0 + KQ;
-    const float* w0 = Wm + (size_t)o * K;
-    const float* w1 = Wm + (size_t)(o + m) * K;
-    const float* ring = state + L.rings + (size_t)D.B * ring_off;
-    const size_t slot2 = (size_t)(t % (2 * dil)) * D.B;            // x[t-2d]
-    const size_t slot1 = (size_t)((t + dil) % (2 * dil)) * D.B;    // x[t-d]
-    auto xptr = [&](int b, int k) -> const float* {
-        if (k < D.W) return ring + (slot2 + b) * D.W + k;
-        if (k < 2 * D.W) return ring + (slot1 + b) * D.W + (k - D.W);
-        if (k < 3 * D.W) return state + L.l + (size_t)b * D.W + (k - 2 * D.W);
-        return enc + ((size_t)b * Tn + ti) * D.Cd + (k - 3 * D.W);
-    };
-    for (int b0 = 0; b0 < D.B; b0 += AR_BT) {
-        float a0[AR_BT], a1[AR_BT];
-#pragma unroll
-        for (int e = 0; e < AR_BT; ++e) a0[e] = a1[e] = 0.f;
-        for (int kc = k0; kc < k1; kc += AR_KC * 256) {
-            f4 wa[AR_KC], wb[AR_KC];
-#pragma unroll
-            for (int i = 0; i < AR_KC; ++i) {
-                const int k = kc + i * 256 + lane * 4;
-                wa[i] = k < k1 ? *reinterpret_cast<const f4*>(w0 + k) : (f4){0.f, 0.f, 0.f, 0.f};
-                wb[i] = k < k1 ? *reinterpret_cast<const f4*>(w1 + k) : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int e = 0; e < AR_BT; ++e) {
-                const int b = b0 + e;
-                if (b >= D.B) break;
-                f4 xv[AR_KC];
-#pragma unroll
-                for (int i = 0; i < AR_KC; ++i) {
-                    const int k = kc + i * 256 + lane * 4;
-                    xv[i] = k < k1 ? *reinterpret_cast<const f4*>(xptr(b, k)) : (f4){0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int i = 0; i < AR_KC; ++i) {
-                    a0[e] += wa[i][0] * xv[i][0] + wa[i][1] * xv[i][1] + wa[i][2] * xv[i][2] + wa[i][3] * xv[i][3];
-                    a1[e] += wb[i][0] * xv[i][0] + wb[i][1] * xv[i][1] + wb[i][2] * xv[i][2] + wb[i][3] * xv[i][3];
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < AR_BT; ++e) {
-            const float s0 = wave_sum(a0[e]), s1 = wave_sum(a1[e]);
-            if (lane == 0) { part[wave][e][0] = s0; part[wave][e][1] = s1; }
-        }
-        __syncthreads();
-        if (threadIdx.x < AR_BT && b0 + (int)threadIdx.x < D.B) {
-            const int e = threadIdx.x;
-            const float hs = part[0][e][0] + part[1][e][0] + part[2][e][0] + part[3][e][0] + bias[o];
-            const float ht = part[0][e][1] + part[1][e][1] + part[2][e][1] + part[3][e][1] + bias[o + m];
-            state[L.g + (size_t)(b0 + e) * m + o] = (1.f / (1.f + expf(-hs))) * tanhf(ht);   // wavenet.py:479
-        }
-        __syncthreads();
-    }
-}
-
-// =====================  merged GEMV step (B < 4): one launch per layer  =====================
+// =====================  GEMV step (B < 4): one launch per layer  =====================
 // A layer needs two dependent phases (pre-activation -> gate -> res/skip), and the step is a chain
 // of launch-latency-bound kernels (~4.7 us each), so the count of dependent launches IS the step
 // time.  With lin_j = lin_{j-1} + Wres_{j-1} m_{j-1} + bres_{j-1} substituted into the current-tap
@@ -343,12 +234,13 @@ __device__ inline GateX gate_x_load(const float* ring2, const float* ring1, cons
 
 // first kernel of a step: lin_0 = conv_start (every workgroup recomputes it: 3 MACs per channel),
 // s = skip_start(lin_0), d_0 = dilated_conv_1 + mel_cond_1 pre-activations.  Rows: [0,S) s, [S,S+G) d.
+// The batch is walked in chunks of AR_GEMV_MAXB (one chunk for the batches this step is chosen for).
 __global__ __launch_bounds__(256) void ar_first_m_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ wav_in,
     const float* __restrict__ forced, int Tn, const float* __restrict__ wb, const float* __restrict__ Wss,
     const float* __restrict__ bss, const float* __restrict__ Wd, const float* __restrict__ bd,
     const float* __restrict__ enc, int per_step, size_t ring_off, int dil) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];          // lin_0 [B][W]
+    extern __shared__ __attribute__((aligned(16))) float sh[];          // lin_0 [chunk][W]
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
     const int lane = threadIdx.x & 63;
@@ -360,52 +252,58 @@ __global__ __launch_bounds__(256) void ar_first_m_kernel(
     const size_t slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.B;    // lin_0[t-d]
     RowW<AR_NCA> wd;
     RowW<AR_NCH> ws;
-    GateX gx[AR_GEMV_MAXB];
     float bias = 0.f;
     if (is_d) {
         wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
-#pragma unroll
-        for (int b = 0; b < AR_GEMV_MAXB; ++b)
-            if (b < D.B)
-                gx[b] = gate_x_load(ring + (slot2 + b) * D.W, ring + (slot1 + b) * D.W,
-                                    enc + ((size_t)b * Tn + ti) * D.Cd, D.W, D.Cd, lane);
         bias = bd[r];
     } else if (is_s) {
         ws = row_load<AR_NCH>(Wss + (size_t)o * D.W, D.W, lane);
         bias = bss[o];
     }
     float* ur = state + L.uring;
-    for (int i = threadIdx.x; i < D.B * D.W; i += 256) {
-        const int b = i / D.W, c = i - b * D.W;
-        float a;
-        if (wav_in) a = wav_in[b];
-        else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
-        else a = t > 0 ? state[L.a_prev + b] : 0.f;                 // fastgen.py:154: audio starts at 0
-        const float u = D.mu ? wn_mu_law_scaled(a) : a;
-        const float u1 = ur[((t + 3) & 3) * D.B + b], u2 = ur[((t + 2) & 3) * D.B + b];
-        const float v = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
-        sh[i] = v;
-        if (blockIdx.x == 0) {
-            state[L.l + i] = v;                                                          // lin_0, buffer 0
-            state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + c] = v;
-            if (c == 0) ur[(t & 3) * D.B + b] = u;
-        }
-    }
-    __syncthreads();
-    if (!is_s && !is_d) return;
+    for (int b0 = 0; b0 < D.B; b0 += AR_GEMV_MAXB) {
+        const int nb = min(AR_GEMV_MAXB, D.B - b0);
+        GateX gx[AR_GEMV_MAXB];
+        if (is_d) {
 #pragma unroll
-    for (int b = 0; b < AR_GEMV_MAXB; ++b) {
-        if (b >= D.B) break;
-        const float* lin = sh + (size_t)b * D.W;
-        if (is_s) {
-            const float v = wave_sum(row_fma<AR_NCH>(ws, D.W, lane, [&](int, int k) {
-                return *reinterpret_cast<const f4*>(lin + k); })) + bias;
-            if (lane == 0) state[L.s + (size_t)b * D.S + o] = v;
-        } else {
-            const float v = wave_sum(row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
-                return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[b].x[i]; })) + bias;
-            if (lane == 0) state[L.dbuf + (size_t)b * D.G + r] = v;                       // d_0, buffer 0
+            for (int e = 0; e < AR_GEMV_MAXB; ++e)
+                if (e < nb)
+                    gx[e] = gate_x_load(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
+                                        enc + ((size_t)(b0 + e) * Tn + ti) * D.Cd, D.W, D.Cd, lane);
         }
+        for (int i = threadIdx.x; i < nb * D.W; i += 256) {
+            const int e = i / D.W, c = i - e * D.W, b = b0 + e;
+            float a;
+            if (wav_in) a = wav_in[b];
+            else if (forced) a = t > 0 ? forced[(size_t)b * Tn + (t - 1)] : 0.f;
+            else a = t > 0 ? state[L.a_prev + b] : 0.f;                 // fastgen.py:154: audio starts at 0
+            const float u = D.mu ? wn_mu_law_scaled(a) : a;
+            const float u1 = ur[((t + 3) & 3) * D.B + b], u2 = ur[((t + 2) & 3) * D.B + b];
+            const float v = wb[3 * D.W + c] + wb[c] * u2 + wb[D.W + c] * u1 + wb[2 * D.W + c] * u;
+            sh[i] = v;
+            if (blockIdx.x == 0) {
+                state[L.l + (size_t)b * D.W + c] = v;                                        // lin_0, buffer 0
+                state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + c] = v;
+                if (c == 0) ur[(t & 3) * D.B + b] = u;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+            if (e >= nb || !(is_s || is_d)) break;
+            const int b = b0 + e;
+            const float* lin = sh + (size_t)e * D.W;
+            if (is_s) {
+                const float v = wave_sum(row_fma<AR_NCH>(ws, D.W, lane, [&](int, int k) {
+                    return *reinterpret_cast<const f4*>(lin + k); })) + bias;
+                if (lane == 0) state[L.s + (size_t)b * D.S + o] = v;
+            } else {
+                const float v = wave_sum(row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                    return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[e].x[i]; })) + bias;
+                if (lane == 0) state[L.dbuf + (size_t)b * D.G + r] = v;                       // d_0, buffer 0
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -416,10 +314,10 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, int cur, const float* __restrict__ Wrs,
     const float* __restrict__ brs, const float* __restrict__ Wd, const float* __restrict__ Wcomp,
     const float* __restrict__ bm, const float* __restrict__ enc, int Tn, int per_step, size_t ring_off, int dil) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];          // m [B][H] | lin_{j-1} [B][W]
+    extern __shared__ __attribute__((aligned(16))) float sh[];          // m [chunk][H] | lin_{j-1} [chunk][W]
     const int H = D.G / 2;
     float* shm = sh;
-    float* shl = sh + (size_t)D.B * H;
+    float* shl = sh + (size_t)AR_GEMV_MAXB * H;
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
     const int lane = threadIdx.x & 63;
@@ -433,63 +331,69 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
     // all global loads of this wave's row are in flight before the gate prologue
     RowW<AR_NCA> wd;
     RowW<AR_NCH> wh;
-    GateX gx[AR_GEMV_MAXB];
     float bias = 0.f;
     if (is_d) {
         wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
         wh = row_load<AR_NCH>(Wcomp + (size_t)r * H, H, lane);
-#pragma unroll
-        for (int b = 0; b < AR_GEMV_MAXB; ++b)
-            if (b < D.B)
-                gx[b] = gate_x_load(ring + (slot2 + b) * D.W, ring + (slot1 + b) * D.W,
-                                    enc + ((size_t)b * Tn + ti) * D.Cd, D.W, D.Cd, lane);
         bias = bm[r];
     } else if (is_rs) {
         wh = row_load<AR_NCH>(Wrs + (size_t)row * H, H, lane);
         bias = brs[row];
     }
-    // skip rows accumulate into s: fetch the old values with the other loads, not after the reduction
-    float sold[AR_GEMV_MAXB];
-#pragma unroll
-    for (int b = 0; b < AR_GEMV_MAXB; ++b)
-        sold[b] = (is_rs && row >= D.W && b < D.B) ? state[L.s + (size_t)b * D.S + (row - D.W)] : 0.f;
     const float* dprev = state + L.dbuf + (size_t)cur * D.B * D.G;
     const float* lprev = state + (cur ? L.l2 : L.l);
-    // gate of the previous layer (wavenet.py:479), recomputed by every workgroup
-    for (int i = threadIdx.x; i < D.B * H; i += 256) {
-        const int b = i / H, k = i - b * H;
-        shm[i] = ar_gate(dprev[(size_t)b * D.G + k], dprev[(size_t)b * D.G + H + k]);
-    }
-    if (!LAST)
-        for (int i = threadIdx.x; i < D.B * D.W; i += 256) shl[i] = lprev[i];
-    __syncthreads();
-    if (!is_rs && !is_d) return;
     const int nxt = cur ^ 1;
+    for (int b0 = 0; b0 < D.B; b0 += AR_GEMV_MAXB) {
+        const int nb = min(AR_GEMV_MAXB, D.B - b0);
+        GateX gx[AR_GEMV_MAXB];
+        float sold[AR_GEMV_MAXB];      // skip rows accumulate into s: fetched with the other loads
 #pragma unroll
-    for (int b = 0; b < AR_GEMV_MAXB; ++b) {
-        if (b >= D.B) break;
-        const float* m = shm + (size_t)b * H;
-        const float* lin = shl + (size_t)b * D.W;
-        if (is_rs) {
-            const float v = wave_sum(row_fma<AR_NCH>(wh, H, lane, [&](int, int k) {
-                return *reinterpret_cast<const f4*>(m + k); })) + bias;
-            if (lane == 0) {
-                if (row < D.W) {
-                    const float ln = lin[row] + v;                                        // wavenet.py:481-485
-                    state[(nxt ? L.l2 : L.l) + (size_t)b * D.W + row] = ln;
-                    // lin_j is the INPUT of layer j: its queue slot of this step (masked.py:357-359)
-                    state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + row] = ln;
-                } else {
-                    state[L.s + (size_t)b * D.S + (row - D.W)] = sold[b] + v;             // wavenet.py:486-490
-                }
+        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+            sold[e] = 0.f;
+            if (e < nb) {
+                if (is_d)
+                    gx[e] = gate_x_load(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
+                                        enc + ((size_t)(b0 + e) * Tn + ti) * D.Cd, D.W, D.Cd, lane);
+                if (is_rs && row >= D.W) sold[e] = state[L.s + (size_t)(b0 + e) * D.S + (row - D.W)];
             }
-        } else {
-            float acc = row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
-                return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[b].x[i]; });
-            acc += row_fma<AR_NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
-            const float v = wave_sum(acc) + bias;
-            if (lane == 0) state[L.dbuf + (size_t)nxt * D.B * D.G + (size_t)b * D.G + r] = v;
         }
+        // gate of the previous layer (wavenet.py:479), recomputed by every workgroup
+        for (int i = threadIdx.x; i < nb * H; i += 256) {
+            const int e = i / H, k = i - e * H;
+            const float* dp = dprev + (size_t)(b0 + e) * D.G;
+            shm[i] = ar_gate(dp[k], dp[H + k]);
+        }
+        if (!LAST)
+            for (int i = threadIdx.x; i < nb * D.W; i += 256) shl[i] = lprev[(size_t)b0 * D.W + i];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+            if (e >= nb || !(is_rs || is_d)) break;
+            const int b = b0 + e;
+            const float* m = shm + (size_t)e * H;
+            const float* lin = shl + (size_t)e * D.W;
+            if (is_rs) {
+                const float v = wave_sum(row_fma<AR_NCH>(wh, H, lane, [&](int, int k) {
+                    return *reinterpret_cast<const f4*>(m + k); })) + bias;
+                if (lane == 0) {
+                    if (row < D.W) {
+                        const float ln = lin[row] + v;                                        // wavenet.py:481-485
+                        state[(nxt ? L.l2 : L.l) + (size_t)b * D.W + row] = ln;
+                        // lin_j is the INPUT of layer j: its queue slot of this step (masked.py:357-359)
+                        state[L.rings + (size_t)D.B * ring_off + ((size_t)(t % (2 * dil + 1)) * D.B + b) * D.W + row] = ln;
+                    } else {
+                        state[L.s + (size_t)b * D.S + (row - D.W)] = sold[e] + v;             // wavenet.py:486-490
+                    }
+                }
+            } else {
+                float acc = row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                    return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[e].x[i]; });
+                acc += row_fma<AR_NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
+                const float v = wave_sum(acc) + bias;
+                if (lane == 0) state[L.dbuf + (size_t)nxt * D.B * D.G + (size_t)b * D.G + r] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -929,15 +833,14 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
     if (L.NB) return ar_enqueue_step_b<4>(h, state, L, D, wav_in, forced, enc, Tn, per_step, rnd, seed, idx, wav, out_params, st);
     const ArPack& P = h->ar;
     const float* blob = h->d_blob;
-    if (B <= AR_GEMV_MAXB && P.layers.size() >= 1 && 3 * D.W + D.Cd <= 256 * AR_NCA && D.G / 2 <= 256 * AR_NCH &&
-        D.W <= 256 * AR_NCH) {
+    {
         // merged step: one launch per layer (see ar_layer_m_kernel)
         const size_t n = P.layers.size();
         const ArLayerPack& l0 = P.layers[0];
-        hipLaunchKernelGGL(ar_first_m_kernel, dim3((D.S + D.G + 3) / 4), dim3(256), (size_t)B * D.W * sizeof(float), st,
+        hipLaunchKernelGGL(ar_first_m_kernel, dim3((D.S + D.G + 3) / 4), dim3(256), (size_t)AR_GEMV_MAXB * D.W * sizeof(float), st,
                            state, L, D, wav_in, forced, Tn, blob + P.start_off, blob + P.wss_off, blob + P.bss_off,
                            blob + l0.wd_off, blob + l0.bd_off, enc, per_step, l0.ring_off, l0.dilation);
-        const size_t shb = (size_t)B * (D.G / 2 + D.W) * sizeof(float);
+        const size_t shb = (size_t)AR_GEMV_MAXB * (D.G / 2 + D.W) * sizeof(float);
         for (size_t j = 1; j < n; ++j) {
             const ArLayerPack& lp = P.layers[j];
             const ArLayerPack& pv = P.layers[j - 1];
@@ -950,32 +853,13 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
                            (int)((n - 1) & 1), blob + pl.wrs_off, blob + pl.brs_off, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, enc, Tn, per_step, (size_t)0, 1);
         hipLaunchKernelGGL(ar_rows_kernel<2>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo1_off,
-                           blob + P.bo1_off, D.S, D.S + D.Cd, enc, Tn, per_step, (size_t)0, 1);
+                           blob + P.bo1_off, D.S, D.S + D.Cd, enc, Tn, per_step);
         hipLaunchKernelGGL(ar_rows_kernel<3>, dim3((D.OW + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo2_off,
-                           blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step, (size_t)0, 1);
+                           blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step);
         hipLaunchKernelGGL(ar_sample_kernel, dim3(B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
                            per_step, Tn, idx, wav, out_params);
         hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
-        return;
     }
-    hipLaunchKernelGGL(ar_start_kernel, dim3((B * D.W + 255) / 256), dim3(256), 0, st, state, L, D, wav_in,
-                       forced, Tn, blob + P.start_off);
-    hipLaunchKernelGGL(ar_rows_kernel<0>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wss_off,
-                       blob + P.bss_off, D.S, D.W, enc, Tn, per_step, (size_t)0, 1);
-    for (const ArLayerPack& lp : P.layers) {
-        hipLaunchKernelGGL(ar_gate_kernel, dim3(D.G / 2), dim3(256), 0, st, state, L, D,
-                           blob + lp.wd_off, blob + lp.bd_off, enc, Tn, per_step, lp.ring_off, lp.dilation);
-        hipLaunchKernelGGL(ar_rows_kernel<1>, dim3((D.W + D.S + 3) / 4), dim3(256), 0, st, state, L, D,
-                           blob + lp.wrs_off, blob + lp.brs_off, D.W + D.S, D.G / 2, enc, Tn, per_step,
-                           lp.ring_off, lp.dilation);
-    }
-    hipLaunchKernelGGL(ar_rows_kernel<2>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo1_off,
-                       blob + P.bo1_off, D.S, D.S + D.Cd, enc, Tn, per_step, (size_t)0, 1);
-    hipLaunchKernelGGL(ar_rows_kernel<3>, dim3((D.OW + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo2_off,
-                       blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step, (size_t)0, 1);
-    hipLaunchKernelGGL(ar_sample_kernel, dim3(B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
-                       per_step, Tn, idx, wav, out_params);
-    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
 }
 
 struct ArGraphCache {
