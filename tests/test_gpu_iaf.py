@@ -135,15 +135,9 @@ def test_full_size_properties_config2():
         wav = _np(a['wav']).astype(np.float64)
         assert np.all(wav * 32768 == np.round(wav * 32768)) and wav.min() >= -1 and wav.max() <= 1 - 2.0 ** -15
         assert np.array_equal(_np(a['idx']), (wav * 32768).astype(np.int32))
-        # oracle on a 4096-sample prefix: causal stack => prefix of the output only needs the
-        # mel frames whose deconv support reaches it (frame <= (crop + 4096 + 50) / 200 + 2)
-        Fp = 32
-        Tp = O.iaf_length(Fp, hp)                                      # 6144, crop 128
-        if crop == 0:
-            continue
-        # build an aligned sub-problem: same mel frames, same noise, same crop offset needed
-    # second check of the prefix property with an explicitly aligned crop (crop 0 both sides)
-    F1, F2 = 64, 384                                                   # T 12800 -> 12800? (64*200 = 12800 = 25*512)
+    # prefix property of the causal stack with an aligned crop (crop 0 on both sides): the first samples of
+    # the long utterance equal the short utterance built from the same leading mel frames and noise
+    F1, F2 = 64, 384                                                   # 64 * 200 = 12800 = 25 * 512
     assert O.iaf_length(F1, hp) == 12800
     mel = np.random.RandomState(5).uniform(0, 1, [1, F2, 80]).astype(np.float32)
     noise = O.logistic_from_uniform(np.random.RandomState(6).uniform(1e-5, 1 - 1e-5, [1, 76800]))
@@ -356,3 +350,29 @@ def test_device_mel_featuriser_matches_host_featuriser():
     host = M.batch_melspectrogram(wavs)
     assert np.abs(_np(dev) - host).max() <= 2e-4
     assert float(dev[2].max()) == float(host[2].max())          # silence sits on the floor (40/140)
+
+
+def test_full_size_batch8_hoisted_conditioning():
+    """BASELINE configs[2] per-GPU share (8 utterances of F=384): the call runs the hoisted
+    conditioning GEMM; every row must equal the single-utterance (fused-kernel) result up to fp32
+    summation order, keep K2 (x == eps*scale_tot + mean_tot) and be reproducible bit for bit."""
+    import torch
+    from oracle import wavenet_np as O
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    eng = _engine(cfgd, w)
+    B, F, T = 8, 384, 76800
+    assert eng.iaf_cond_hoisted(B, F) and not eng.iaf_cond_hoisted(1, F)
+    mel = np.random.RandomState(12345).uniform(0, 1, [B, F, 80]).astype(np.float32)
+    noise = O.logistic_from_uniform(np.random.RandomState(12346).uniform(1e-5, 1 - 1e-5, [B, T]))
+    a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot', 'rand_input', 'wav'))
+    b = eng.iaf_generate(mel, noise, want=('x',))
+    assert torch.equal(a['x'], b['x'])
+    x, m, s, r = (_np(a[k]).astype(np.float64) for k in ('x', 'mean_tot', 'scale_tot', 'rand_input'))
+    assert np.all(np.isfinite(x)) and np.all(s > 0)
+    assert np.abs(x - (r * s + m)).max() <= 1e-6 * max(1.0, np.abs(x).max())
+    for row in (0, 5):
+        one = _np(eng.iaf_generate(mel[row:row + 1], noise[row:row + 1], want=('x',))['x'])
+        assert np.abs(one[0] - x[row]).max() <= 5e-6 * max(1.0, np.abs(one).max())
+    eng.close()
