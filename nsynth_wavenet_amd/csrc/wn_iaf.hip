@@ -648,7 +648,10 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         }
         // row blocks of this flow inside C (all flows when the deconv stack is shared)
         const float* Cf = Cc + (c.share_deconv ? (size_t)fp.rb_base * rb_floats : 0);
-        if (f16x3) {
+        // fused f16x3 form: the start conv runs inside the first layer kernel of the flow (dilation 1)
+        const bool fuse_start = f16x3 && !hoist && !fp.layers.empty() && fp.layers[0].dilation == 1;
+        if (fuse_start) {
+        } else if (f16x3) {
             wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st);
         } else {
             dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
@@ -672,7 +675,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                 wn_iaf_c_layer(lin, lout, Cf + li * rb_floats, L.c_bstride, h->d_blob + lp.off_h, L.RS, lp.dilation, B,
                                L.T, h->num_cu, st);
             else if (f16x3)
-                wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st);
+                wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st,
+                               (li == 0 && fuse_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off);
             else
                 hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
                                    lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,

@@ -54,10 +54,14 @@ __global__ __launch_bounds__(256) void iaf_start_h_kernel(const float* __restric
 }
 
 // ---------------- fused residual layer ----------------
-template <int HN>
+// FIRST (first layer of a flow, HN = 1, d = 1): the l operands are computed from the flow input x
+// (start conv fused in), lin is not read.
+template <int HN, bool FIRST = false>
 __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const unsigned* __restrict__ enc,
-    const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int c0, int d, int tiles_per_row, int ntiles) {
+    const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int c0, int d, int tiles_per_row, int ntiles,
+    const float* __restrict__ x, int XR, const float* __restrict__ wstart) {
+    static_assert(!FIRST || HN == 1, "the fused start conv is written for 64-sample tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int TILE = 64 * HN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,7 +92,9 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
         KOp<HN> o;
 #pragma unroll
         for (int e = 0; e < HN; ++e) {
-            if (ks < 6) {
+            if (FIRST && ks < 6) {
+                o.h[e] = o.l[e] = (wn_u4){0u, 0u, 0u, 0u};          // filled by first_layer_operands
+            } else if (ks < 6) {
                 o.h[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 16 * e, (4 * (ks & 1)) * RS16);
                 o.l[e] = buf_ld4(s.rl, s.vo[ks >> 1] + 16 * e, (8 + 4 * (ks & 1)) * RS16);
             } else {
@@ -104,13 +110,32 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     KOp<HN> bc[14];
     const TileWalk tw = tile_walk(ntiles);
     const int tile0 = tw.first, tstep = tw.step, tend = tw.end;
+    // FIRST: x[t-5 .. t-1] of this lane's column, one tile ahead like the other operands
+    const f4* wq = reinterpret_cast<const f4*>(ldsw + IAF_LAYER_H_WORDS);
+    float xv[5];
+    auto load_x = [&](int tile) {
+        const int b = tile / tiles_per_row;
+        const int t = (tile - b * tiles_per_row) * TILE + wave * 16 + n;
+        const float* xp = x + (size_t)b * XR + IAF_XP + t;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) xv[j] = xp[j - 5];
+    };
     if (tile0 < tend) {
         const HSrc s0 = tile_src(tile0);
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) bc[ks] = loadK(s0, ks);
+        if (FIRST) load_x(tile0);
     }
     // the weight image is staged AFTER the first tile's operand loads are in flight
+    if (FIRST) stage_start_weights(wstart, reinterpret_cast<f4*>(ldsw + IAF_LAYER_H_WORDS));
     stage_words<IAF_LAYER_H_WORDS>(wpack, ldsw);
+    if (FIRST && tile0 < tend) {
+        const int b0 = tile0 / tiles_per_row;
+        KOp<1> f6[6];
+        first_layer_operands(xv, (long long)(tile0 - b0 * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) { bc[ks].h[0] = f6[ks].h[0]; bc[ks].l[0] = f6[ks].l[0]; }
+    }
     const float inv_m = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 128], inv_r = ldsf[IAF_P_FLOATS + IAF_PR_FLOATS + 129];
     for (int tile = tile0; tile < tend; tile += tstep) {
         const int b = tile / tiles_per_row;
@@ -118,6 +143,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
         const int next = tile + tstep;
         const bool has_next = next < tend;
         const HSrc sn = tile_src(has_next ? next : tile);
+        if (FIRST && has_next) load_x(next);
 
         f4 acc[4][HN];
 #pragma unroll
@@ -148,7 +174,15 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                     acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 12 * HN, 0);
-            if (has_next) bc[ks] = loadK(sn, ks);
+            if (has_next && !(FIRST && ks < 6)) bc[ks] = loadK(sn, ks);
+            if (FIRST && ks == 5 && has_next) {
+                // the l operands of the next tile, computed while the enc K-steps keep the MFMA pipe busy
+                const int bn = next / tiles_per_row;
+                KOp<1> f6[6];
+                first_layer_operands(xv, (long long)(next - bn * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6);
+#pragma unroll
+                for (int k2 = 0; k2 < 6; ++k2) { bc[k2].h[0] = f6[k2].h[0]; bc[k2].l[0] = f6[k2].l[0]; }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue per column tile: gate, residual 1x1, split, store
@@ -444,6 +478,9 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
 int wn_iaf_h_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_H_WORDS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (IAF_LAYER_H_WORDS + IAF_START_LDS_WORDS) * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_h_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_H_WORDS * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_h_kernel<1>),
@@ -468,16 +505,28 @@ static int pick_hn(int B, int64_t T, int num_cu) {
     return c1 < c2 ? 1 : 2;
 }
 
+// x != nullptr: first layer of a flow -- the start conv is evaluated inside the kernel from the flow
+// input x (row stride XR) with the start weights wstart, lin is not read
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st) {
-    const int hn = pick_hn(B, T, num_cu);
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, const float* x, int XR,
+                    const float* wstart) {
+    const int hn = x ? 1 : pick_hn(B, T, num_cu);
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    auto kern = hn == 1 ? iaf_layer_h_kernel<1> : iaf_layer_h_kernel<2>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st,
-                       reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout),
-                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wpack), RS, TE, c0, d,
-                       tiles_per_row, ntiles);
+    const unsigned* li = reinterpret_cast<const unsigned*>(lin);
+    unsigned* lo = reinterpret_cast<unsigned*>(lout);
+    const unsigned* en = reinterpret_cast<const unsigned*>(enc);
+    const unsigned* wp = reinterpret_cast<const unsigned*>(wpack);
+    if (x)
+        hipLaunchKernelGGL((iaf_layer_h_kernel<1, true>), dim3(grid), dim3(256),
+                           (IAF_LAYER_H_WORDS + IAF_START_LDS_WORDS) * 4, st, li, lo, en, wp, RS, TE, c0, d, tiles_per_row,
+                           ntiles, x, XR, wstart);
+    else if (hn == 1)
+        hipLaunchKernelGGL((iaf_layer_h_kernel<1, false>), dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st, li, lo, en, wp,
+                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart);
+    else
+        hipLaunchKernelGGL((iaf_layer_h_kernel<2, false>), dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st, li, lo, en, wp,
+                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart);
 }
 
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,

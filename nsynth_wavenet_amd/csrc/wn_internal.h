@@ -174,7 +174,8 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
 int wn_iaf_h_set_attrs(wn_handle* h);
 void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st);
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st);
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, const float* x = nullptr, int XR = 0,
+                    const float* wstart = nullptr);
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
                    int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T);

@@ -91,6 +91,39 @@ __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int 
 }
 
 
+// Operands of the FIRST residual layer of a flow (dilation 1), computed from the flow input instead
+// of being loaded: the layer's input is l0 = start_conv(shift_right(x)) (parallel_wavenet.py:222-225),
+// l0[c][t'] = b[c] + w0[c] x[t'-3] + w1[c] x[t'-2] + w2[c] x[t'-1], and 0 left of the utterance.
+// xv[j] = x[t-5+j]; wq[c] = (w0, w1, w2, b) in LDS; bc[2*tap + s] = K-step operands of tap t-2+tap.
+constexpr int IAF_START_LDS_WORDS = 64 * 4;
+__device__ inline void first_layer_operands(const float (&xv)[5], long long t, int kg, const f4* __restrict__ wq,
+                                            KOp<1> (&bc)[6]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 2 * (16 * s + 8 * (i >> 1) + 2 * kg + (i & 1));
+            const f4 wa = wq[c], wb = wq[c + 1];
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                float v0 = wa[3] + wa[0] * xv[tap] + wa[1] * xv[tap + 1] + wa[2] * xv[tap + 2];
+                float v1 = wb[3] + wb[0] * xv[tap] + wb[1] * xv[tap + 1] + wb[2] * xv[tap + 2];
+                if (t - 2 + tap < 0) v0 = v1 = 0.f;
+                unsigned hw, lw;
+                wn_split_pair(v0, v1, hw, lw);
+                bc[2 * tap + s].h[0][i] = hw;
+                bc[2 * tap + s].l[0][i] = lw;
+            }
+        }
+}
+// stage (w0, w1, w2, b) per channel from the start-conv block w[3][64] | b[64]
+__device__ inline void stage_start_weights(const float* __restrict__ wb, f4* wq) {
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        wq[c] = (f4){wb[c], wb[64 + c], wb[128 + c], wb[192 + c]};
+    }
+}
+
 __device__ inline float softplus_tf(float p) {
     const float thr = -13.942384719848633f;      // tf.nn.softplus: log(eps) + 2
     if (p > -thr) return p;
