@@ -41,19 +41,21 @@ PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
-def pmc_traffic(B, F, precision='f16x3'):
-    """HBM bytes per iaf_layer_kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
+def pmc_traffic(B, F, precision='f16x3', hoisted=False):
+    """HBM bytes per launch of the dominant layer kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
     PMC counters cannot be collected from inside this process, so this is the value of the
-    profiled run of the SAME command; None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json' if precision == 'f32' else 'r01_pmc_summary_f16x3.json')
+    profiled run of the SAME command; None when the workload differs from a profiled one."""
+    name, kernel = (('r01_pmc_summary.json', 'iaf_layer_kernel') if precision == 'f32' else
+                    ('r01_pmc_summary_f16x3_batch8_hoisted.json', 'iaf_layer_c_kernel') if hoisted else
+                    ('r01_pmc_summary_f16x3.json', 'iaf_layer_h_kernel'))
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
             d = json.load(f)
         w = d['workload']
         if (w['batch_per_gpu'], w['frames']) != (B, F):
             return None
-        return d['kernels']['iaf_layer_kernel' if precision == 'f32' else 'iaf_layer_h_kernel']['hbm_bytes_per_launch']
+        return d['kernels'][kernel]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
@@ -202,7 +204,7 @@ def main():
                     'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                     'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
             dtype = 'f32'
-        roof.update({'traffic': None if hoisted else pmc_traffic(B, F, eng.precision),
+        roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted),
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
                      'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
                      'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
