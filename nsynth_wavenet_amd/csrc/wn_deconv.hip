@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
 #pragma unroll
         for (int kl = 0; kl < DH_KC; ++kl) {
             const int j = tg * DH_KC + kl;
-            if (j >= taps) break;
+            if (j < taps) {                       // (a guard, not a break: keeps the loop fully unrolled)
             if (j > 0) {
                 // operands one column to the left: e -> e+1, e = 0 from the neighbour lane / halo
                 const wn_u4 th = vh[DC_NT - 1], tl = vl[DC_NT - 1];
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
                     cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
                     acc[mb][e] = cc;
                 }
+            }
             }
         }
         if (chunk + 1 < nchunk) stage_store(chunk + 1, buf ^ 1);
