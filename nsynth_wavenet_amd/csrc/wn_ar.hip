@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
 //   d_j = Wd_j[t-2d] ring_j(t-2d) + Wd_j[t-d] ring_j(t-d) + Wd_j[t] lin_{j-1} + (Wd_j[t] Wres_{j-1}) m_{j-1}
 //         + Wc_j enc + (bd_j + bc_j + Wd_j[t] bres_{j-1}),
 // every row of {lin_j, s += skip_{j-1}, d_j} depends only on lin_{j-1}, d_{j-1} (m_{j-1} = gate(d_{j-1})
-// is recomputed by every workgroup: 512 sigmoid*tanh) and on ring / enc data of earlier steps:
+// is recomputed by every workgroup: gate_width/2 sigmoid*tanh) and on ring / enc data of earlier steps:
 // ONE kernel per layer, 34 launches per step instead of 65.  Same arithmetic up to fp32
 // re-association of the current-tap term; lin_j itself is computed exactly as before.
 //   rings: slot = step mod (2d+1), so the slot pushed at step t is not the one holding t-2d.
