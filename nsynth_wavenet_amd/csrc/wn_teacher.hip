@@ -8,7 +8,7 @@
 //   s, out1   : fp32 in the MFMA accumulator layout [t/16][16-row block][lane][4] -- written and
 //               read-modify-written with one 16-byte access per lane, and the accumulator
 //               registers of two row blocks ARE the B operand of a K-step of the next GEMM
-// One kernel template: C[64 rows][256 columns] per workgroup, K walked over up to four operand
+// One kernel template: C[64 or 128 rows][256 columns] per workgroup, K walked over up to four operand
 // segments (three dilated taps of l + enc; m; relu(s) + enc; relu(out1)), weights as A fragments
 // staged through LDS in double-buffered chunks shared by the four waves.  Epilogues: gate ->
 // m; residual add -> l and skip accumulate -> s; plain store; time-major out_params.
@@ -58,31 +58,37 @@ struct TgArgs {
     int ow;
 };
 
-template <int EPI>
+// U = 64-row m-tiles per workgroup (1 or 2): two tiles halve the re-reads of the activation operand,
+// which bound the kernel (each operand word is fetched once per workgroup row of the grid).
+template <int EPI, int U>
 __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned lds[2][TG_KC * 4 * 512];
+    constexpr int KC = TG_KC / U;                 // K-steps per LDS stage (64 KB in both shapes)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const int mt = blockIdx.y, b = blockIdx.z;
+    const int mt0 = blockIdx.y * U, b = blockIdx.z;
     const int t0 = blockIdx.x * TG_TN + wave * 16 * TG_NT;      // first column of this wave
-    const int nchunk = (a.nks + TG_KC - 1) / TG_KC;
+    const int nchunk = (a.nks + KC - 1) / KC;
 
-    f4 acc[4][TG_NT];
+    f4 acc[4 * U][TG_NT];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4 * U; ++mb)
 #pragma unroll
         for (int e = 0; e < TG_NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const wn_u4* wsrc = reinterpret_cast<const wn_u4*>(a.wp) + (size_t)mt * a.nks * 512;
+    const wn_u4* wsrc = reinterpret_cast<const wn_u4*>(a.wp);
     auto stage = [&](int chunk, int buf) {
 #pragma unroll
-        for (int kl = 0; kl < TG_KC; ++kl) {
-            const int ks = chunk * TG_KC + kl;
+        for (int kl = 0; kl < KC; ++kl) {
+            const int ks = chunk * KC + kl;
             if (ks < a.nks) {
-                const wn_u4* src = wsrc + (size_t)ks * 512;
-                wn_u4* dst = reinterpret_cast<wn_u4*>(lds[buf]) + kl * 512;
-                dst[threadIdx.x] = src[threadIdx.x];
-                dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const wn_u4* src = wsrc + ((size_t)(mt0 + u) * a.nks + ks) * 512;
+                    wn_u4* dst = reinterpret_cast<wn_u4*>(lds[buf]) + (kl * U + u) * 512;
+                    dst[threadIdx.x] = src[threadIdx.x];
+                    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+                }
             }
         }
     };
@@ -127,29 +133,34 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
         if (chunk + 1 < nchunk) stage(chunk + 1, buf ^ 1);
         const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
 #pragma unroll
-        for (int kl = 0; kl < TG_KC; ++kl) {
-            const int ks = chunk * TG_KC + kl;
-            if (ks >= a.nks) break;
-            wn_u4 vh[TG_NT], vl[TG_NT];
+        for (int kl = 0; kl < KC; ++kl) {
+            const int ks = chunk * KC + kl;
+            if (ks < a.nks) {
+                wn_u4 vh[TG_NT], vl[TG_NT];
 #pragma unroll
-            for (int e = 0; e < TG_NT; ++e) { vh[e] = b1h[e]; vl[e] = b1l[e]; }
-            if (ks + 1 < a.nks) loadB(ks + 1, b1h, b1l);
+                for (int e = 0; e < TG_NT; ++e) { vh[e] = b1h[e]; vl[e] = b1l[e]; }
+                if (ks + 1 < a.nks) loadB(ks + 1, b1h, b1l);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const wn_u4 ah = Al[(kl * 4 + mb) * 128], al = Al[(kl * 4 + mb) * 128 + 64];
+                for (int mb = 0; mb < 4 * U; ++mb) {
+                    const wn_u4 ah = Al[(kl * 4 * U + mb) * 128], al = Al[(kl * 4 * U + mb) * 128 + 64];
 #pragma unroll
-                for (int e = 0; e < TG_NT; ++e) acc[mb][e] = mfma3(ah, al, vh[e], vl[e], acc[mb][e]);
+                    for (int e = 0; e < TG_NT; ++e) acc[mb][e] = mfma3(ah, al, vh[e], vl[e], acc[mb][e]);
+                }
             }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: row 16 mb + 4 q + r of the m-tile, column t0 + 16 e + n ----
+    // ---- epilogue per 64-row tile: row 16 mb + 4 q + r of the tile, column t0 + 16 e + n ----
+    const float inv = a.inv_scale;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int mt = mt0 + u;
     const f4* bias4 = reinterpret_cast<const f4*>(a.bias + (size_t)mt * 64) + q;
     f4 bv[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) bv[mb] = bias4[mb * 4];
-    const float inv = a.inv_scale;
+    f4 (&ac)[4][TG_NT] = *reinterpret_cast<f4 (*)[4][TG_NT]>(&acc[4 * u]);
     if (EPI == TG_EPI_GATE) {
         // rows 0-31: sigmoid half of gate channels 32 mt .. +31, rows 32-63: their tanh half
         wn_u4* o = reinterpret_cast<wn_u4*>(a.og4 + (size_t)b * a.og4_bstride) +
@@ -165,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
                     float g[2];
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
-                        g[k] = sigmoidf_(fmaf(acc[mg][e][2 * rp + k], inv, bv[mg][2 * rp + k])) *
-                               tanhf_(fmaf(acc[mg + 2][e][2 * rp + k], inv, bv[mg + 2][2 * rp + k]));
+                        g[k] = sigmoidf_(fmaf(ac[mg][e][2 * rp + k], inv, bv[mg][2 * rp + k])) *
+                               tanhf_(fmaf(ac[mg + 2][e][2 * rp + k], inv, bv[mg + 2][2 * rp + k]));
                     unsigned hw, lw;
                     wn_split_pair(g[0], g[1], hw, lw);
                     gh[2 * mg + rp] = hw;
@@ -193,8 +204,8 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
                         const int mb = 2 * st + mg;
                         float l0, l1;
                         wn_join_pair(oh[2 * mg + rp], ol[2 * mg + rp], l0, l1);
-                        l0 += fmaf(acc[mb][e][2 * rp], inv, bv[mb][2 * rp]);
-                        l1 += fmaf(acc[mb][e][2 * rp + 1], inv, bv[mb][2 * rp + 1]);
+                        l0 += fmaf(ac[mb][e][2 * rp], inv, bv[mb][2 * rp]);
+                        l1 += fmaf(ac[mb][e][2 * rp + 1], inv, bv[mb][2 * rp + 1]);
                         unsigned hw, lw;
                         wn_split_pair(l0, l1, hw, lw);
                         nh[2 * mg + rp] = hw;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
                 f4* p = o + ((size_t)e * a.oacc_nmb + mb) * 64;
                 f4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[mb][e][r], inv, bv[mb][r]);
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(ac[mb][e][r], inv, bv[mb][r]);
                 if (EPI == TG_EPI_RS) v += *p;
                 *p = v;
             }
@@ -232,9 +243,10 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 64 * mt + 16 * mb + 4 * q + r;
-                    if (c < a.ow) o[c] = fmaf(acc[mb][e][r], inv, bv[mb][r]);
+                    if (c < a.ow) o[c] = fmaf(ac[mb][e][r], inv, bv[mb][r]);
                 }
         }
+    }
     }
 }
 
@@ -313,8 +325,13 @@ TLayout t_layout(const wn_handle* h, int B, int F, long long T) {
 
 template <int EPI>
 void tg_launch(const TgArgs& a, int mtiles, int B, long long Tp, hipStream_t st) {
-    dim3 g((unsigned)(Tp / TG_TN), mtiles, B);
-    hipLaunchKernelGGL(tg_gemm_kernel<EPI>, g, dim3(256), 0, st, a);
+    if (mtiles % 2 == 0) {
+        dim3 g((unsigned)(Tp / TG_TN), mtiles / 2, B);
+        hipLaunchKernelGGL((tg_gemm_kernel<EPI, 2>), g, dim3(256), 0, st, a);
+    } else {
+        dim3 g((unsigned)(Tp / TG_TN), mtiles, B);
+        hipLaunchKernelGGL((tg_gemm_kernel<EPI, 1>), g, dim3(256), 0, st, a);
+    }
 }
 
 }  // namespace
