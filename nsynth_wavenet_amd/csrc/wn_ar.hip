@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
 // Weights are packed in A-fragment order ([row block][k-group of 16][lane][4], one coalesced
 // 16-byte load per lane = 4 K-steps of v_mfma_f32_16x16x4_f32); activations are [feature][NB].
 // One workgroup = one 16-row block x one chunk of 16*NT batch columns; its four waves split K
-// (the step is a chain of ~62 latency-bound launches: more, shorter waves) and meet in LDS.
+// (the step is a chain of latency-bound launches: more, shorter waves) and meet in LDS.
 
 __global__ void ar_start_b_kernel(float* __restrict__ state, ArStateLayout L, ArDims D,
                                   const float* __restrict__ wav_in, const float* __restrict__ forced,
