@@ -1,7 +1,7 @@
 """CPU stand-in for the reference's fastgen loop at full width (numpy restatement), dev tool."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import wavenet_np as O
 d = json.load(open(os.path.join(ROOT, 'config_jsons', 'wavenet_mol.json')))
