@@ -64,7 +64,7 @@ def main():
                'config': {'workload': 'BASELINE.json configs[3]: wavenet_mol.json fastgen, {} utterance(s) x {} samples, '
                                       'Philox sampling on device'.format(B, Tn),
                           'us_per_sample_step': us_step, 'x_realtime_per_utterance': Tn / dt / 16000.0,
-                          'launches_per_step': (hp.num_layers + 5) if B < 4 else (2 * hp.num_layers + 6)},
+                          'launches_per_step': (hp.num_layers + 4) if B < 4 else (2 * hp.num_layers + 5)},
                'roofline': {'bound': 'hbm', 'achieved': wbytes / (us_step * 1e-6) / 1e9, 'peak': PEAK_HBM_GBPS,
                             'unit': 'GB/s', 'frac': wbytes / (us_step * 1e-6) / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                             'note': 'weight bytes streamed per step / step time; the step is a chain of dependent '

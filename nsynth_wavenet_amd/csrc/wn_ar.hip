@@ -14,10 +14,10 @@
 // Two step implementations, chosen by batch size:
 //  * B < 4: wave-per-output-row GEMV kernels, activations [batch][feature], ONE launch per
 //    layer (ar_layer_m_kernel: the residual update is substituted into the next layer's
-//    current-tap term, so a layer is a single dependent phase) -- 35 launches per step;
+//    current-tap term, so a layer is a single dependent phase) -- 34 launches per step;
 //  * B >= 4: the batch is the N dimension of v_mfma_f32_16x16x4_f32 (activations
 //    [feature][padded batch]), so one pass over the 119 MB of weights serves every utterance
-//    (two launches per layer, 66 per step).
+//    (two launches per layer, 65 per step).
 // Both are chains of dependent, launch-latency-bound kernels.
 #include <cstdlib>
 #include <cstring>
@@ -491,6 +491,14 @@ __global__ __launch_bounds__(256) void ar_sample_kernel(
         state[L.a_prev + b] = a;
         if (idx) idx[(size_t)b * Tn + ti] = q;
         if (wav) wav[(size_t)b * Tn + ti] = a;
+        // the last workgroup to get here advances the step counter (every workgroup read it at its
+        // start, before taking a ticket): no separate launch for the increment
+        unsigned* ticket = reinterpret_cast<unsigned*>(state) + 4;
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0u;
+            *reinterpret_cast<long long*>(state) = t + 1;
+        }
     }
 }
 
@@ -749,10 +757,6 @@ __global__ void ar_frag_dc_kernel(const float* __restrict__ wd, const float* __r
     dst[i] = k < KA ? wd[(size_t)row * KA + k] : wcomp[(size_t)row * H + (k - KA)];
 }
 
-__global__ void ar_advance_kernel(float* state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *reinterpret_cast<long long*>(state) += 1;
-}
-
 ArDims ar_dims(const wn_handle* h, int B) {
     const wn_config& c = h->cfg;
     ArDims D;
@@ -820,7 +824,6 @@ void ar_enqueue_step_b(wn_handle* h, float* state, const ArStateLayout& L, const
                        blob + P.wo2_b_off, blob + P.bo2_off, D.OW, D.S);
     hipLaunchKernelGGL(ar_sample_kernel, dim3(D.B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
                        per_step, Tn, idx, wav, out_params);
-    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
 }
 
 void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, const float* forced,
@@ -858,8 +861,7 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
                            blob + P.bo2_off, D.OW, D.S, enc, Tn, per_step);
         hipLaunchKernelGGL(ar_sample_kernel, dim3(B), dim3(256), 0, st, state, L, D, rnd, wn_ar_n_rand(h), seed,
                            per_step, Tn, idx, wav, out_params);
-        hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(64), 0, st, state);
-    }
+        }
 }
 
 struct ArGraphCache {
