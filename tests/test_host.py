@@ -257,3 +257,17 @@ def test_run_all_eval_staging_and_sweep(tmp_path, monkeypatch):
         rae.run_all(str(sweep), str(tmp_path), str(tmp_path / 'out'), '0')
     with pytest.raises(ValueError):
         real_syn_wave('rm_rf.py', 'a', 'b', 'c', '0')
+
+
+def test_precision_names_map_to_config_fields():
+    hp = cfg.load_hparams(REFERENCE_STYLE_STUDENT)
+    for name, (prec, cond) in {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}.items():
+        c = cfg.to_wn_config(hp, precision=name)
+        assert (c.precision, c.cond_mode, c.use_resize_conv) == (prec, cond, 0) and list(c.reserved) == [0] * 5
+    with pytest.raises(ValueError):
+        cfg.to_wn_config(hp, precision='bf16')
+    lib = _lib.load()
+    c = cfg.to_wn_config(hp)
+    c.cond_mode = 7
+    assert lib.wn_create(ctypes.byref(c), ctypes.byref(ctypes.c_void_p(0))) == -22
+    assert b'conditioning mode' in lib.wn_last_error(None)
