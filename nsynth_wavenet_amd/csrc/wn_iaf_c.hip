@@ -23,6 +23,20 @@
 #include "wn_codec.h"
 #include "wn_mfma_h.h"
 
+// Cache policy of the accesses to the hoisted term C: it is written once and read once, 1.3 GB per
+// utterance later, so both sides are marked non-temporal (aux bit 1 = nt) and do not displace the
+// residual stream in L2.  Measured at 8 utterances: the GEMM 3.85 -> 3.19 ms, the layer kernel
+// 103.7 -> 98.7 us.
+#ifndef WN_C_ST_AUX
+#define WN_C_ST_AUX 2
+#endif
+#ifndef WN_C_LD_AUX
+#define WN_C_LD_AUX 2
+#endif
+#ifndef WN_ENC_STAGE_AUX
+#define WN_ENC_STAGE_AUX 0
+#endif
+
 namespace {
 
 constexpr int CK_NC = 128;                       // columns of one conditioning-GEMM task
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             for (int c4 = 0; c4 < 64 / RP / 4; ++c4) {
                 wn_u4 tmp[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) tmp[p] = buf_ld4(re, vo, (RP * (4 * c4 + p)) * TE16);
+                for (int p = 0; p < 4; ++p) tmp[p] = buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_NC + col] = tmp[p];
             }
@@ -118,7 +132,8 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 const int cb = (CK_NC / 16) * j + nb;
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
-                    buf_st4(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16, (cb * 4 + mb) * 1024);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,
+                                                           (cb * 4 + mb) * 1024, WN_C_ST_AUX);
             };
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -162,7 +177,7 @@ struct CSrc {
 };
 
 __device__ inline f4 buf_ldf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, WN_C_LD_AUX));
 }
 
 // ---------------- residual layer with hoisted conditioning ----------------
