@@ -1,0 +1,71 @@
+"""Randomised cross-checks of the execution forms against each other on the GPU (dev tool; run through
+gpurun: `python tests/tools/fuzz_gpu.py [seconds]`).  Student: auto / fused / hoisted / fp32 on random
+(batch, frames); teacher: GEMV step vs batched step vs full-sequence forward on random (batch, length)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from nsynth_wavenet_amd import weights as wts, config as cfg
+from nsynth_wavenet_amd.engine import Engine
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+rs = np.random.RandomState(int(time.time()) & 0xffff)
+bad = 0
+t_end = time.time() + budget / 2
+d = json.load(open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json')))
+hp = cfg.load_hparams(d)
+w = wts.synthetic_weights(hp, seed=int(rs.randint(1 << 20)), init='unit' if rs.rand() < 0.5 else 'tf')
+engs = {p: Engine(d, precision=p).load_weights(w) for p in ('f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32')}
+n = 0
+while time.time() < t_end:
+    B, F = int(rs.randint(1, 13)), int(rs.randint(3, 451))
+    mel = torch.rand(B, F, 80, device='cuda')
+    a = engs['f16x3'].iaf_generate(mel, None, seed=n, want=('x', 'rand_input', 'mean_tot', 'scale_tot'))
+    if a['x'].shape[1] == 0:
+        continue
+    scale = max(1.0, float(a['x'].abs().max()))
+    k2 = float((a['x'].double() - (a['rand_input'].double() * a['scale_tot'].double() + a['mean_tot'].double())).abs().max())
+    worst = 0.0
+    for p in ('f16x3-fused', 'f16x3-hoisted', 'f32'):
+        x = engs[p].iaf_generate(mel, a['rand_input'], want=('x',))['x']
+        worst = max(worst, float((x - a['x']).abs().max()))
+    ok = worst <= 2e-5 * scale and k2 <= 2e-6 * scale and bool(torch.isfinite(a['x']).all())
+    bad += not ok
+    n += 1
+    if not ok or n % 10 == 0:
+        print('student B=%d F=%d T=%d maxdiff %.2e K2 %.1e scale %.1f %s' % (B, F, a['x'].shape[1], worst, k2, scale, 'ok' if ok else 'BAD'), flush=True)
+for e in engs.values():
+    e.close()
+print('student cases', n, 'bad', bad)
+
+td = json.load(open(os.path.join(ROOT, 'config_jsons', 'wavenet_mol.json')))
+td.update(dict(width=128, skip_width=64, deconv_width=64, num_layers=7, num_stages=3, deconv_config=[[8, 2], [12, 4]]))
+thp = cfg.load_hparams(td)
+tw = wts.synthetic_weights(thp, 'teacher', seed=3, init='unit')
+t_end = time.time() + budget / 2
+m = 0
+while time.time() < t_end:
+    B, F = int(rs.randint(1, 41)), int(rs.randint(2, 30))
+    Tn = F * 8
+    mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    outs = {}
+    for mode in ('gemv', 'mfma'):
+        os.environ['WN_AR_MODE'] = mode
+        eng = Engine(td).load_weights(tw)
+        enc = eng.deconv(mel)
+        outs[mode] = eng.ar_generate(enc, forced_wav=forced, want_out=True)['out_params'].clone()
+        if mode == 'mfma':
+            outs['fwd'] = eng.teacher_forward(forced, mel).clone()
+        eng.close()
+    os.environ.pop('WN_AR_MODE')
+    sc = max(1.0, float(outs['fwd'].abs().max()))
+    e1 = float((outs['gemv'] - outs['mfma']).abs().max()); e2 = float((outs['gemv'] - outs['fwd']).abs().max())
+    ok = e1 <= 2e-5 * sc and e2 <= 5e-5 * sc
+    bad += not ok
+    m += 1
+    if not ok or m % 5 == 0:
+        print('teacher B=%d Tn=%d gemv-mfma %.2e gemv-forward %.2e %s' % (B, Tn, e1, e2, 'ok' if ok else 'BAD'), flush=True)
+print('teacher cases', m, 'TOTAL bad', bad)
+sys.exit(1 if bad else 0)
