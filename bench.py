@@ -108,8 +108,8 @@ def cpu_baseline(hp_dict, frames, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch-per-gpu', type=int, default=1)
     ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
