@@ -114,6 +114,8 @@ def main():
     ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layer-events-every', type=int, default=4,
+                    help='record the HIP-event pairs around the layer kernels in every n-th timed step')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     args = ap.parse_args()
@@ -158,6 +160,8 @@ def main():
     eng.profile_begin()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # the event pairs around the layer kernels cost the stream a bubble each: sample them
+        eng.profile_pause(i % max(args.layer_events_every, 1) != 0)
         wav = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0

@@ -206,12 +206,6 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
                    const float* forced_wav, float* out_params,
                    void* ws, size_t ws_bytes, void* stream);
 
-/* Measurement aid used by bench.py (not part of the reference's surface, not
- * thread-safe).  Between begin and end, wn_iaf_generate records a hipEvent pair
- * on the caller's stream around every flow's run of residual-layer kernels
- * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
- * summed elapsed milliseconds and the number of layer-kernel launches they
- * bracket, so that average launch duration = layer_ms / layer_launches. */
 /* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher
  * handle: wav [B,T] raw audio in [-1,1] (the input encoding of wavenet.py:412-418 -- mu-law/128 when
  * use_mu_law -- is applied on the device), mel [B,F,n_mel]; out_params [B,T,out_width] are the
@@ -227,7 +221,17 @@ int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, int B, 
  * deconv stack (the layer kernels then stream 768 B/sample instead of 1536), else 0. */
 int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
+/* Measurement aid used by bench.py (not part of the reference's surface, not
+ * thread-safe).  Between begin and end, wn_iaf_generate records a hipEvent pair
+ * on the caller's stream around every flow's run of residual-layer kernels
+ * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
+ * summed elapsed milliseconds and the number of layer-kernel launches they
+ * bracket, so that average launch duration = layer_ms / layer_launches..
+ * Every recorded event costs the stream a bubble of a few microseconds, so
+ * wn_profile_pause(h, 1) suspends the recording for the following calls (0 resumes):
+ * bench.py samples every few steps of its timed region instead of all of them. */
 int wn_profile_begin(wn_handle* h);
+int wn_profile_pause(wn_handle* h, int paused);
 int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches);
 
 /* Last error message of this handle (or of wn_create when h == NULL). */

@@ -749,6 +749,12 @@ extern "C" int wn_profile_begin(wn_handle* h) {
     return WN_OK;
 }
 
+extern "C" int wn_profile_pause(wn_handle* h, int paused) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_pause: null handle");
+    h->prof_on = !paused;
+    return WN_OK;
+}
+
 extern "C" int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_end: null handle");
     h->prof_on = false;

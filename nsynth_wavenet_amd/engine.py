@@ -184,6 +184,9 @@ class Engine(object):
     def profile_begin(self):
         self._check(self.lib.wn_profile_begin(self._h))
 
+    def profile_pause(self, paused):
+        self._check(self.lib.wn_profile_pause(self._h, 1 if paused else 0))
+
     def profile_end(self):
         """-> (summed ms of the bracketed residual-layer kernel runs, number of launches)."""
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
