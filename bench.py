@@ -182,8 +182,9 @@ def main():
         achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
         hoisted = eng.iaf_cond_hoisted(B, F)
         if hoisted:
-            # conditioning 1x1s hoisted into one GEMM per deconv stack (large batches): the layer
-            # kernel streams l in/out and the projected term, 768 B/sample
+            # conditioning 1x1s hoisted into one GEMM per deconv stack (the default): the layer
+            # kernel streams l in/out and the projected term, 768 B/sample; the event pairs bracket the
+            # single-layer launches only (36 of the 60 layers; the other 24 run two per launch)
             bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
             achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
             roof = {'kernel': 'iaf_layer_c_kernel (dilated conv + gate + residual 1x1 on hoisted conditioning, split-fp16 MFMA)',

@@ -340,6 +340,283 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
     }
 }
 
+// ---------------- two residual layers in one launch (small dilations) ----------------
+// Layers (A, B) with dilations (d, 2d), 4d <= 16.  A wave walks a contiguous run of 16-column
+// blocks: layer A's block output (the four 16-byte operand words a lane holds after the epilogue)
+// IS layer B's tap-t operand in the same lane, and B's taps t-2d, t-4d are column shifts of at most
+// one block -- a DPP row shift of the current block's words merged with a row rotate of the previous
+// block's, all in registers.  Layer A's output never goes to memory: 256 (l) + 2 x 256 (C) + 256
+// (l out) = 1024 B/sample for two layers instead of 2 x 768, and one launch floor instead of two.
+// A run starts one block early (layer A only) to have a previous block; left of the utterance the
+// previous block is zero like the padded l rows.  Eight waves per workgroup (two per SIMD): one
+// wave's gate/split VALU work overlaps the other's MFMAs; operands are reloaded for the next block
+// into the registers that were just consumed.
+// FIRST: layer A is the first layer of a flow and its operands are computed from the flow input x
+// (start conv fused in, see first_layer_operands).
+constexpr int PC_THREADS = 512;
+constexpr int PC_LDS_WORDS = 2 * LC_LDS_WORDS + IAF_START_LDS_WORDS;
+
+struct PairLayer {
+    const wn_u4* Pl;
+    const wn_u4* PRl;
+    const float* bg;
+    const float* br;
+    float inv_m, inv_r;
+};
+
+// gate + residual 1x1 + skip of one 16-column block: acc -> new l as operand words (oh, ol);
+// lh/ll: the layer's tap-t operand words (K-steps 4, 5) = its input l
+__device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], const wn_u4 (&lh)[2], const wn_u4 (&ll)[2],
+                                     wn_u4 (&oh)[2], wn_u4 (&ol)[2]) {
+    float g[2][4];
+#pragma unroll
+    for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            g[mg][r] = sigmoidf_(fmaf(acc[mg][r], w.inv_m, w.bg[mg * 4 + r])) *
+                       tanhf_(fmaf(acc[mg + 2][r], w.inv_m, w.bg[(mg + 2) * 4 + r]));
+    wn_u4 gh, gl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hw, lw;
+        wn_split_pair(g[i >> 1][(i & 1) * 2], g[i >> 1][(i & 1) * 2 + 1], hw, lw);
+        gh[i] = hw;
+        gl[i] = lw;
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f4 rc = mfma3(w.PRl[(mb * 2 + 0) * 64], w.PRl[(mb * 2 + 1) * 64], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            float l0, l1;
+            wn_join_pair(lh[mb >> 1][(mb & 1) * 2 + rp], ll[mb >> 1][(mb & 1) * 2 + rp], l0, l1);
+            const float v0 = l0 + fmaf(rc[2 * rp], w.inv_r, w.br[mb * 4 + 2 * rp]);
+            const float v1 = l1 + fmaf(rc[2 * rp + 1], w.inv_r, w.br[mb * 4 + 2 * rp + 1]);
+            unsigned hw, lw;
+            wn_split_pair(v0, v1, hw, lw);
+            oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
+            ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
+        }
+    }
+}
+
+// column shift by SH (1..16) of a block's words: lane n gets cur[n - SH], or prev[n - SH + 16]
+template <int SH>
+__device__ inline wn_u4 pair_shift(wn_u4 prev, wn_u4 cur) {
+    if (SH == 16) return prev;
+    wn_u4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rot = __builtin_amdgcn_update_dpp(0, (int)prev[i], 0x120 + (SH & 15), 0xf, 0xf, true);   // row_ror:SH
+        o[i] = (unsigned)__builtin_amdgcn_update_dpp(rot, (int)cur[i], 0x110 + (SH & 15), 0xf, 0xf, false);  // row_shr:SH
+    }
+    return o;
+}
+
+template <int DB, bool FIRST>
+__global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
+    const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ CA,
+    const float* __restrict__ CB, int64_t c_bstride, const unsigned* __restrict__ wA, const unsigned* __restrict__ wB,
+    int64_t RS, int NB, int rl, int rpr, int ntasks, const float* __restrict__ x, int XR,
+    const float* __restrict__ wstart) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    constexpr int DA = DB / 2, NW = PC_THREADS / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const float* ldsf = reinterpret_cast<const float*>(ldsw);
+    PairLayer LA, LB;
+    LA.Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;
+    LA.PRl = LA.Pl + 6 * 4 * 2 * 64;
+    LA.bg = ldsf + LC_A_WORDS + IAF_PR_FLOATS + q * 16;
+    LA.br = LA.bg + 64;
+    LB.Pl = reinterpret_cast<const wn_u4*>(ldsw + LC_LDS_WORDS) + lane;
+    LB.PRl = LB.Pl + 6 * 4 * 2 * 64;
+    LB.bg = ldsf + LC_LDS_WORDS + LC_A_WORDS + IAF_PR_FLOATS + q * 16;
+    LB.br = LB.bg + 64;
+    const f4* wq = reinterpret_cast<const f4*>(ldsw + 2 * LC_LDS_WORDS);
+    const int RS16 = (int)RS * 16;
+    const int lane_l = q * RS16 + (n + IAF_LP) * 16;
+
+    // task walk: each XCD takes one contiguous eighth of the runs
+    int first, end, step;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, per = (ntasks + 7) >> 3;
+        first = xcd * per + (int)(blockIdx.x >> 3) * NW + wave;
+        end = min(ntasks, (xcd + 1) * per);
+        step = (int)(gridDim.x >> 3) * NW;
+    } else {
+        first = (int)blockIdx.x * NW + wave;
+        end = ntasks;
+        step = (int)gridDim.x * NW;
+    }
+
+    // operands of the block being computed; every register is reloaded for the next block right after its
+    // last use.  The loads are unconditional: "no next block" is an offset past the end of the descriptor
+    // (returns zeros, moves nothing) -- a branch around a load makes the compiler drain vmcnt at the join.
+    constexpr int OOB = 0x40000000;
+    KOp<1> bc[6];
+    f4 caA[4], cbA[4], caB[4], cbB[4];          // C tiles ping-pong (the accumulators take over their registers)
+    float xvA[5], xvB[5];
+    int b = 0, s = 0, e = 0;
+    __amdgpu_buffer_rsrc_t rl_, rca, rcb, ro, rx;
+    auto set_run = [&](int task) {
+        b = task / rpr;
+        s = (task - b * rpr) * rl;
+        e = min(NB, s + rl);
+        rl_ = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        ro = __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        rca = __builtin_amdgcn_make_buffer_rsrc((void*)(CA + (size_t)b * c_bstride), 0, NB * 4096, 0x00020000);
+        rcb = __builtin_amdgcn_make_buffer_rsrc((void*)(CB + (size_t)b * c_bstride), 0, NB * 4096, 0x00020000);
+        if (FIRST) rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * XR), 0, XR * 4, 0x00020000);
+    };
+    auto load_c = [&](const __amdgpu_buffer_rsrc_t& r, f4 (&c)[4], int k, int pred) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) c[mb] = buf_ldf4(r, lane * 16 + k * 4096 + pred, mb * 1024);
+    };
+    auto load_bc = [&](int k, int ks, int pred) {
+        const int vo = lane_l + (16 * k - (2 - (ks >> 1)) * DA) * 16 + pred;
+        bc[ks].h[0] = buf_ld4(rl_, vo, (4 * (ks & 1)) * RS16);
+        bc[ks].l[0] = buf_ld4(rl_, vo, (8 + 4 * (ks & 1)) * RS16);
+    };
+    auto load_x = [&](float (&xv)[5], int k, int pred) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  rx, (IAF_XP + 16 * k + n + j - 5) * 4 + pred, 0, 0));
+    };
+    auto load_all = [&](int k) {
+        load_c(rca, caA, k, 0);
+        load_c(rcb, cbA, k, k >= s ? 0 : OOB);
+        if (FIRST) {
+            load_x(xvA, k, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) load_bc(k, ks, 0);
+        }
+    };
+    // K loop of one layer: acc starts from c; B operands through op(ks); after(ks) runs once the K-step is issued
+    auto contract = [&](const PairLayer& w, f4 (&acc)[4], auto&& op, auto&& after) {
+        wn_u4 a[2][4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            a[0][mb][0] = w.Pl[((0 * 4 + mb) * 2 + 0) * 64];
+            a[0][mb][1] = w.Pl[((0 * 4 + mb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            if (ks + 1 < 6) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = w.Pl[(((ks + 1) * 4 + mb) * 2 + 0) * 64];
+                    a[(ks + 1) & 1][mb][1] = w.Pl[(((ks + 1) * 4 + mb) * 2 + 1) * 64];
+                }
+            }
+            wn_u4 bh, bl;
+            op(ks, bh, bl);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bh, bl, acc[mb]);
+            after(ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (first < end) {
+        set_run(first);
+        load_all(s > 0 ? s - 1 : 0);
+    }
+    // both weight images are staged AFTER the first block's operand loads are in flight
+    if (FIRST) stage_start_weights(wstart, reinterpret_cast<f4*>(ldsw + 2 * LC_LDS_WORDS));
+    {
+        // 16-byte words of one layer image: fragments and tail are contiguous in LDS; in the blob the tail
+        // sits at IAF_P_FLOATS.  All loads of a thread are issued before its first LDS store.
+        constexpr int NV = LC_LDS_WORDS / 4, NCH = (NV + PC_THREADS - 1) / PC_THREADS;
+        static_assert(LC_LDS_WORDS % 4 == 0, "");
+        const wn_u4* sa = reinterpret_cast<const wn_u4*>(wA);
+        const wn_u4* sb = reinterpret_cast<const wn_u4*>(wB);
+        wn_u4* dst = reinterpret_cast<wn_u4*>(ldsw);
+        wn_u4 ta[NCH], tb[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = c * PC_THREADS + (int)threadIdx.x;
+            const int src = i < LC_A_WORDS / 4 ? i : i - LC_A_WORDS / 4 + IAF_P_FLOATS / 4;
+            if (i < NV) { ta[c] = sa[src]; tb[c] = sb[src]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = c * PC_THREADS + (int)threadIdx.x;
+            if (i < NV) { dst[i] = ta[c]; dst[NV + i] = tb[c]; }
+        }
+        __syncthreads();
+    }
+    LA.inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
+    LA.inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
+    LB.inv_m = ldsf[LC_LDS_WORDS + LC_A_WORDS + IAF_PR_FLOATS + 128];
+    LB.inv_r = ldsf[LC_LDS_WORDS + LC_A_WORDS + IAF_PR_FLOATS + 129];
+
+    for (int task = first; task < end; task += step) {
+        if (task != first) {
+            set_run(task);
+            load_all(s > 0 ? s - 1 : 0);
+        }
+        wn_u4 ph[2], pl[2];                     // layer A's output of the previous block
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) ph[s2] = pl[s2] = (wn_u4){0u, 0u, 0u, 0u};
+        auto block = [&](int k, f4 (&ca)[4], f4 (&cb)[4], float (&xv)[5], f4 (&can)[4], f4 (&cbn)[4], float (&xvn)[5]) {
+            const int pred = k + 1 < e ? 0 : OOB;
+            // ---- layer A ----
+            if (FIRST) {
+                first_layer_operands(xv, (long long)16 * k + n, q, wq, bc);
+                load_x(xvn, k + 1, pred);
+            }
+            f4 acc[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = ca[mb];
+            load_c(rca, can, k + 1, pred);
+            wn_u4 th[2], tl[2];                 // tap-t words: the residual's skip input
+            contract(LA, acc,
+                     [&](int ks, wn_u4& bh, wn_u4& bl) {
+                         bh = bc[ks].h[0];
+                         bl = bc[ks].l[0];
+                         if (ks >= 4) { th[ks - 4] = bh; tl[ks - 4] = bl; }
+                     },
+                     [&](int ks) { if (!FIRST) load_bc(k + 1, ks, pred); });
+            wn_u4 oh[2], ol[2];
+            pair_epilogue(LA, acc, th, tl, oh, ol);
+            // ---- layer B ----
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = cb[mb];
+            load_c(rcb, cbn, k + 1, pred);
+            if (k >= s) {
+                contract(LB, acc,
+                         [&](int ks, wn_u4& bh, wn_u4& bl) {
+                             const int s2 = ks & 1;
+                             if (ks < 2) { bh = pair_shift<2 * DB>(ph[s2], oh[s2]); bl = pair_shift<2 * DB>(pl[s2], ol[s2]); }
+                             else if (ks < 4) { bh = pair_shift<DB>(ph[s2], oh[s2]); bl = pair_shift<DB>(pl[s2], ol[s2]); }
+                             else { bh = oh[s2]; bl = ol[s2]; }
+                         },
+                         [&](int) {});
+                wn_u4 qh[2], ql[2];
+                pair_epilogue(LB, acc, oh, ol, qh, ql);
+                const int vo_out = lane_l + 16 * k * 16;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    buf_st4(qh[s2], ro, vo_out, (4 * s2) * RS16);
+                    buf_st4(ql[s2], ro, vo_out, (8 + 4 * s2) * RS16);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { ph[s2] = oh[s2]; pl[s2] = ol[s2]; }
+        };
+        int k = s > 0 ? s - 1 : 0;
+        while (k < e) {
+            block(k, caA, cbA, xvA, caB, cbB, xvB);
+            if (++k >= e) break;
+            block(k, caB, cbB, xvB, caA, cbA, xvA);
+            ++k;
+        }
+    }
+}
+
 // ---------------- flow head with hoisted conditioning (parallel_wavenet.py:256-277, :319-324) ----------------
 template <int HN>
 __global__ __launch_bounds__(256, 2) void iaf_head_c_kernel(
@@ -483,6 +760,12 @@ int pick_hn_c(int B, int64_t T, int slots) {
 int wn_iaf_c_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_cond_h_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_WORDS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_WORDS * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<8, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_WORDS * 4));
     return WN_OK;
 }
 
@@ -528,6 +811,29 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
                        tiles_per_row, ntiles);
+}
+
+// Two layers (dilations da, db = 2 da, 4 da <= 16) in one launch; x != nullptr: layer A is the first
+// layer of a flow (da = 1) and the start conv runs inside.
+bool wn_iaf_c_pair_ok(int da, int db) { return db == 2 * da && (db == 2 || db == 8) && !getenv("WN_NO_PAIR"); }
+
+void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
+                   const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,
+                   const float* x, int XR, const float* wstart) {
+    const int NB = (int)(T / 16);
+    const int64_t nw = (int64_t)num_cu * (PC_THREADS / 64);
+    const int64_t want = std::max<int64_t>(1, nw / B);       // runs per row that give every wave one run
+    const char* mr = getenv("WN_PAIR_MINRUN");
+    int rl = (int)((NB + want - 1) / want);
+    rl = std::max(rl, mr ? atoi(mr) : 3);                    // bounds the one-block warm-up of a run to a third
+    const int rpr = (NB + rl - 1) / rl;
+    const int64_t ntasks = (int64_t)B * rpr;
+    int grid = (int)std::min<int64_t>(num_cu, (ntasks + PC_THREADS / 64 - 1) / (PC_THREADS / 64));
+    if (grid >= 8) grid = std::min(num_cu, (grid + 7) / 8 * 8);
+    auto kern = db == 2 ? (x ? iaf_pair_c_kernel<2, true> : iaf_pair_c_kernel<2, false>) : iaf_pair_c_kernel<8, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PC_THREADS), PC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
+                       reinterpret_cast<unsigned*>(lout), CA, CB, c_bstride, reinterpret_cast<const unsigned*>(wA),
+                       reinterpret_cast<const unsigned*>(wB), RS, NB, rl, rpr, (int)ntasks, x, XR, wstart);
 }
 
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,

@@ -278,16 +278,16 @@ def test_split_fp16_is_as_accurate_as_fp32():
 
 
 def test_conditioning_placement_policy():
-    """The default 'f16x3' engine picks the conditioning placement per call: fused layer kernels
-    while enc + l fit the Infinity Cache, the hoisted GEMM beyond (wn_iaf.hip wn_iaf_hoisted).
-    Both forms are the same arithmetic up to fp32 summation order; the forced engines reproduce
-    the automatic choice bit for bit."""
+    """The default 'f16x3' engine hoists the per-layer conditioning 1x1s into one GEMM per deconv
+    stack (wn_iaf.hip wn_iaf_hoisted); 'f16x3-fused' keeps them inside the layer kernels.  Both
+    forms are the same arithmetic up to fp32 summation order; the forced engine reproduces the
+    default bit for bit."""
     from oracle import wavenet_np as O
     cfgd = load_json('parallel_wavenet.json')
     hp = O.HP(cfgd)
     w = O.synth_weights(hp, 'student', seed=1234, init='tf')
     auto, fused, hoisted = (_engine(cfgd, w, p) for p in ('f16x3', 'f16x3-fused', 'f16x3-hoisted'))
-    assert not auto.iaf_cond_hoisted(1, 384) and auto.iaf_cond_hoisted(8, 384)
+    assert auto.iaf_cond_hoisted(1, 384) and auto.iaf_cond_hoisted(8, 384)
     assert not fused.iaf_cond_hoisted(8, 384) and hoisted.iaf_cond_hoisted(1, 8)
     rs = np.random.RandomState(9)
     mel = rs.uniform(0, 1, [3, 80, 80]).astype(np.float32)           # T = 15872 per row
@@ -296,16 +296,38 @@ def test_conditioning_placement_policy():
     xa = _np(auto.iaf_generate(mel, noise, want=('x',))['x'])
     xf = _np(fused.iaf_generate(mel, noise, want=('x',))['x'])
     xh = _np(hoisted.iaf_generate(mel, noise, want=('x',))['x'])
-    assert np.array_equal(xa, xf)                                     # small call -> fused
+    assert np.array_equal(xa, xh)
     assert np.abs(xh - xf).max() <= 2e-6 * max(1.0, np.abs(xf).max())
-    big = np.tile(mel, (4, 5, 1))                                     # 12 rows x 400 frames: > 256 MB of enc + l
-    Tb = O.iaf_length(400, hp)
-    assert auto.iaf_cond_hoisted(12, 400)
-    nb = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [12, Tb]))
-    assert np.array_equal(_np(auto.iaf_generate(big, nb, want=('x',))['x']),
-                          _np(hoisted.iaf_generate(big, nb, want=('x',))['x']))
     for e in (auto, fused, hoisted):
         e.close()
+
+
+def test_layer_pairs_match_single_layer_launches(monkeypatch):
+    """Hoisted form: layers with dilations (1,2) and (4,8) run two per launch (wn_iaf_c_pair, layer A's
+    output stays in registers, the start conv of a flow runs inside the first pair).  WN_NO_PAIR=1
+    launches every layer on its own; both must agree to fp32 rounding of the start conv, on shapes
+    that give one run per wave, several runs per row, ragged last runs and several rows."""
+    from oracle import wavenet_np as O
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=4321, init='tf')
+    eng = _engine(cfgd, w, 'f16x3')
+    rs = np.random.RandomState(77)
+    for B, F in ((1, 8), (1, 35), (3, 80), (2, 391), (5, 13)):
+        T = O.iaf_length(F, hp)
+        mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
+        noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
+        monkeypatch.delenv('WN_NO_PAIR', raising=False)
+        a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
+        a = {k: _np(v) for k, v in a.items()}
+        monkeypatch.setenv('WN_NO_PAIR', '1')
+        b = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
+        b = {k: _np(v) for k, v in b.items()}
+        for k in a:
+            assert np.isfinite(a[k]).all()
+            assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(1.0, np.abs(b[k]).max()), (B, F, k)
+    monkeypatch.delenv('WN_NO_PAIR', raising=False)
+    eng.close()
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
@@ -363,7 +385,7 @@ def test_full_size_batch8_hoisted_conditioning():
     w = O.synth_weights(hp, 'student', seed=1234, init='tf')
     eng = _engine(cfgd, w)
     B, F, T = 8, 384, 76800
-    assert eng.iaf_cond_hoisted(B, F) and not eng.iaf_cond_hoisted(1, F)
+    assert eng.iaf_cond_hoisted(B, F)
     mel = np.random.RandomState(12345).uniform(0, 1, [B, F, 80]).astype(np.float32)
     noise = O.logistic_from_uniform(np.random.RandomState(12346).uniform(1e-5, 1 - 1e-5, [B, T]))
     a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot', 'rand_input', 'wav'))
