@@ -58,16 +58,19 @@ typedef _Float16 wn_h2 __attribute__((ext_vector_type(2)));
 typedef unsigned wn_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
 
-// (x0, x1) -> hi word {f16(x0), f16(x1)} and lo word of the remainders
+// (x0, x1) -> hi word {f16(x0), f16(x1)} and lo word of the remainders.  The remainder x - hi is
+// exact in fp32, so v_fma_mix{lo,hi}_f16 (f16 source widened inside the FMA, result rounded once to
+// f16) gives the same bits as convert / subtract / convert in half the instructions; same for the
+// join with v_fma_mix_f32 (checked bit for bit on the device: scripts/ubench/split_codec.hip).
 __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    hi = __builtin_bit_cast(unsigned, (wn_h2){h0, h1});
-    lo = __builtin_bit_cast(unsigned, (wn_h2){l0, l1});
+    hi = __builtin_bit_cast(unsigned, (wn_h2){(_Float16)x0, (_Float16)x1});
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
 }
 
 __device__ inline void wn_join_pair(unsigned hi, unsigned lo, float& x0, float& x1) {
-    const wn_h2 h = __builtin_bit_cast(wn_h2, hi), l = __builtin_bit_cast(wn_h2, lo);
-    x0 = (float)h[0] + (float)l[0];
-    x1 = (float)h[1] + (float)l[1];
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(hi), "v"(lo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(hi), "v"(lo));
 }

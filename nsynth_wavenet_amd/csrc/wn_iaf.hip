@@ -680,6 +680,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
             return WN_OK;
         };
         size_t li = 0;
+        bool head_done = false;
         for (size_t i = 0; i < fp.layers.size(); ++i) {
             const IafLayerPack& lp = fp.layers[i];
             if (hoist && i + 1 < fp.layers.size() && wn_iaf_c_pair_ok(lp.dilation, fp.layers[i + 1].dilation)) {
@@ -691,6 +692,16 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                 float* t = lin; lin = lout; lout = t;
                 li += 2;
                 ++i;
+                continue;
+            }
+            if (hoist && i + 1 == fp.layers.size() && wn_iaf_c_last_ok()) {
+                // last layer of the flow: the head runs in its epilogue
+                if (int rc = prof_mark(false, 0)) return rc;
+                wn_iaf_c_layer_head(lin, Cf + li * rb_floats, Cf + (li + 1) * rb_floats, L.c_bstride,
+                                    h->d_blob + lp.off_h, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.XR, lp.dilation,
+                                    k == 0 ? 1 : 0, B, L.T, h->num_cu, st);
+                head_done = true;
+                ++li;
                 continue;
             }
             if (int rc = prof_mark(true, 1)) return rc;
@@ -708,7 +719,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
             ++li;
         }
         if (int rc = prof_mark(false, 0)) return rc;
-        if (hoist)
+        if (head_done) {
+        } else if (hoist)
             wn_iaf_c_head(lin, Cf + li * rb_floats, L.c_bstride, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.XR, L.T,
                           k == 0 ? 1 : 0, B, h->num_cu, st);
         else if (f16x3)

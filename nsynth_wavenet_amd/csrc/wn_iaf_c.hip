@@ -171,7 +171,7 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
 }
 
 struct CSrc {
-    __amdgpu_buffer_rsrc_t rl, rc;
+    __amdgpu_buffer_rsrc_t rl, rc, rh;
     int vo[3];
     int vc;
 };
@@ -183,10 +183,24 @@ __device__ inline f4 buf_ldf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 // ---------------- residual layer with hoisted conditioning ----------------
 // Same contraction as iaf_layer_h_kernel minus its eight enc K-steps: the accumulators start
 // from the C tile.  Column map of a wave: 16 HN columns, column block e = columns 16e..16e+15.
-template <int HN>
+// LAST: the layer is the last one of its flow -- the flow head (out1 over relu(l), relu, mean / scale
+// projections, x <- x*s + m, running mean_tot / scale_tot; parallel_wavenet.py:256-277, :319-324) runs
+// in the epilogue on the accumulator registers: the layer's output is neither written nor read back.
+struct HeadArgs {
+    const float* Ch;            // hoisted conditioning rows of the head
+    const unsigned* wpack;      // head weight image
+    float* x;
+    float* Mt;
+    float* St;
+    int XR;
+    int64_t T;
+    int first;
+};
+
+template <int HN, bool LAST = false>
 __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
-    const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles) {
+    const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int TILE = 64 * HN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
         s.vo[1] = lane_l + (tt - d) * 16;
         s.vo[2] = lane_l + tt * 16;
         s.vc = lane_c + tt * 256;
+        if (LAST) s.rh = __builtin_amdgcn_make_buffer_rsrc((void*)(ha.Ch + (size_t)b * c_bstride), 0, 0x7ffffff0, 0x00020000);
         return s;
     };
     // K-steps 0-5: taps t-2d, t-d, t (two 32-channel steps each)
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
 
     // Operand double buffer: ALL loads of tile k+1 are issued before tile k is computed, so a
     // workgroup keeps one full tile (48 KB) in flight for the whole tile period.
-    auto load_tile = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN]) {
+    auto load_tile = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN], f4 (&ch)[4][HN]) {
         const CSrc s = tile_src(tile);
 #pragma unroll
         for (int e = 0; e < HN; ++e)
@@ -233,15 +248,29 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
             for (int mb = 0; mb < 4; ++mb) cp[mb][e] = buf_ldf4(s.rc, s.vc + (e * 4 + mb) * 1024, 0);
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) bc[ks] = loadK(s, ks);
+        if (LAST) {
+#pragma unroll
+            for (int e = 0; e < HN; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) ch[mb][e] = buf_ldf4(s.rh, s.vc + (e * 4 + mb) * 1024, 0);
+        }
     };
     const TileWalk tw = tile_walk(ntiles);
     const int tstep = tw.step, tend = tw.end;
     float inv_m = 0.f, inv_r = 0.f;
 
-    auto body = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN], KOp<HN> (&bn)[6], f4 (&cn)[4][HN]) {
+    // head weights / constants (LAST): second image behind the layer's
+    const wn_u4* PHl = reinterpret_cast<const wn_u4*>(ldsw + LC_LDS_WORDS) + lane;
+    const float* bo = ldsf + LC_LDS_WORDS + HC_A_WORDS + q * 16;
+    const float* wm = bo + 64;
+    const float* wsc = wm + 64;
+    float bmean = 0.f, bscale = 0.f, inv_h = 0.f;
+
+    auto body = [&](int tile, KOp<HN> (&bc)[6], f4 (&cp)[4][HN], f4 (&ch)[4][HN], KOp<HN> (&bn)[6], f4 (&cn)[4][HN],
+                    f4 (&chn)[4][HN]) {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * TILE;
-        if (tile + tstep < tend) load_tile(tile + tstep, bn, cn);
+        if (tile + tstep < tend) load_tile(tile + tstep, bn, cn, chn);
         f4 acc[4][HN];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -314,28 +343,82 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
                     ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
                 }
             }
+            if (!LAST) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                buf_st4(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
-                buf_st4(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    buf_st4(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
+                    buf_st4(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
+                }
+            } else {
+                // ---- flow head on this column block (same arithmetic as iaf_head_c_kernel) ----
+                f4 hacc[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) hacc[mb] = ch[mb][e];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    wn_u4 bh = oh[ks], bl = ol[ks];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {             // relu(l) (:256) on the reconstructed value
+                        float v0, v1;
+                        wn_join_pair(bh[i], bl[i], v0, v1);
+                        unsigned hw, lw;
+                        wn_split_pair(fmaxf(v0, 0.f), fmaxf(v1, 0.f), hw, lw);
+                        bh[i] = hw;
+                        bl[i] = lw;
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        hacc[mb] = mfma3(PHl[((ks * 4 + mb) * 2 + 0) * 64], PHl[((ks * 4 + mb) * 2 + 1) * 64], bh, bl, hacc[mb]);
+                }
+                float pm = 0.f, ps = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float o = fmaxf(fmaf(hacc[mb][r], inv_h, bo[mb * 4 + r]), 0.f);
+                        pm = fmaf(wm[mb * 4 + r], o, pm);
+                        ps = fmaf(wsc[mb * 4 + r], o, ps);
+                    }
+                pm += __shfl_xor(pm, 16);
+                ps += __shfl_xor(ps, 16);
+                pm += __shfl_xor(pm, 32);
+                ps += __shfl_xor(ps, 32);
+                if (q == 0) {
+                    const int64_t t = tt + wave * 16 * HN + 16 * e + n;
+                    const float mean = pm + bmean;
+                    const float sc = fminf(fmaxf(softplus_tf(ps + bscale), EXP_M9), EXP_7);   // :105-114
+                    float* xp = ha.x + (size_t)b * ha.XR + IAF_XP + t;
+                    *xp = *xp * sc + mean;                                                    // :277
+                    float* mp = ha.Mt + (size_t)b * ha.T + t;
+                    float* sp = ha.St + (size_t)b * ha.T + t;
+                    if (ha.first) { *mp = mean; *sp = sc; }
+                    else { *mp = mean + *mp * sc; *sp = *sp * sc; }                           // :322-323
+                }
             }
         }
     };
 
     KOp<HN> bA[6], bB[6];
-    f4 cA[4][HN], cB[4][HN];
+    f4 cA[4][HN], cB[4][HN], hA[4][HN], hB[4][HN];
     int tile = tw.first;
-    if (tile < tend) load_tile(tile, bA, cA);
+    if (tile < tend) load_tile(tile, bA, cA, hA);
     // the weight image is staged AFTER the first tile's operand loads are in flight
     stage_words<LC_A_WORDS>(wpack, ldsw);
     stage_words<LC_TAIL_WORDS>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
+    if (LAST) {
+        stage_words<HC_A_WORDS>(ha.wpack, ldsw + LC_LDS_WORDS);
+        stage_words<HC_TAIL_WORDS>(ha.wpack + IAF_PH_FLOATS, ldsw + LC_LDS_WORDS + HC_A_WORDS);
+        bmean = ldsf[LC_LDS_WORDS + HC_A_WORDS + 192];
+        bscale = ldsf[LC_LDS_WORDS + HC_A_WORDS + 193];
+        inv_h = ldsf[LC_LDS_WORDS + HC_A_WORDS + 194];
+    }
     inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
     inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
     while (tile < tend) {
-        body(tile, bA, cA, bB, cB);
+        body(tile, bA, cA, hA, bB, cB, hB);
         tile += tstep;
         if (tile >= tend) break;
-        body(tile, bB, cB, bA, cA);
+        body(tile, bB, cB, hB, bA, cA, hA);
         tile += tstep;
     }
 }
@@ -760,6 +843,8 @@ int pick_hn_c(int B, int64_t T, int slots) {
 int wn_iaf_c_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_cond_h_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_c_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (LC_LDS_WORDS + HC_LDS_WORDS) * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_WORDS * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, true>),
@@ -788,6 +873,7 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
         const double cost = (double)rounds * (ch / NW + 0.5);    // +0.5: staging the enc tile
         if (cost < best_cost) { best_cost = cost; best_n = nch; }
     }
+    if (const char* e = getenv("WN_COND_NCH")) best_n = std::max(1, atoi(e));
     const int ch = ((R + best_n - 1) / best_n + NW - 1) / NW * NW;
     const int nchunks = (R + ch - 1) / ch;
     const int64_t ntasks = (int64_t)ntiles * nchunks;
@@ -810,7 +896,21 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
     auto kern = hn == 1 ? iaf_layer_c_kernel<1> : iaf_layer_c_kernel<2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
-                       tiles_per_row, ntiles);
+                       tiles_per_row, ntiles, HeadArgs{});
+}
+
+// Last layer of a flow with the flow head in its epilogue (64-sample tiles, two workgroups per CU).
+bool wn_iaf_c_last_ok() { return !getenv("WN_NO_HEADFUSE"); }
+
+void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int64_t c_bstride, const float* wpack,
+                         const float* wpack_head, float* x, float* Mt, float* St, int64_t RS, int XR, int d, int first,
+                         int B, int64_t T, int num_cu, hipStream_t st) {
+    const int tiles_per_row = (int)(T / 64), ntiles = B * tiles_per_row;
+    const int grid = ntiles < 2 * num_cu ? ntiles : 2 * num_cu;
+    HeadArgs ha{Ch, reinterpret_cast<const unsigned*>(wpack_head), x, Mt, St, XR, T, first};
+    hipLaunchKernelGGL((iaf_layer_c_kernel<1, true>), dim3(grid), dim3(256), (LC_LDS_WORDS + HC_LDS_WORDS) * 4, st,
+                       reinterpret_cast<const unsigned*>(lin), static_cast<unsigned*>(nullptr), C, c_bstride,
+                       reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, ha);
 }
 
 // Two layers (dilations da, db = 2 da, 4 da <= 16) in one launch; x != nullptr: layer A is the first

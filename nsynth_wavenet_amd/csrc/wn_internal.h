@@ -185,6 +185,10 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
                    int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st);
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
                     int d, int B, int64_t T, int num_cu, hipStream_t st);
+bool wn_iaf_c_last_ok();
+void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int64_t c_bstride, const float* wpack,
+                         const float* wpack_head, float* x, float* Mt, float* St, int64_t RS, int XR, int d, int first,
+                         int B, int64_t T, int num_cu, hipStream_t st);
 bool wn_iaf_c_pair_ok(int da, int db);
 void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
                    const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,

@@ -318,15 +318,22 @@ def test_layer_pairs_match_single_layer_launches(monkeypatch):
         mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
         noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
         monkeypatch.delenv('WN_NO_PAIR', raising=False)
+        monkeypatch.delenv('WN_NO_HEADFUSE', raising=False)
         a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
         a = {k: _np(v) for k, v in a.items()}
         monkeypatch.setenv('WN_NO_PAIR', '1')
         b = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
         b = {k: _np(v) for k, v in b.items()}
+        # ... and the flow head as its own launch instead of the last layer's epilogue: same arithmetic
+        monkeypatch.setenv('WN_NO_HEADFUSE', '1')
+        c = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
+        c = {k: _np(v) for k, v in c.items()}
         for k in a:
             assert np.isfinite(a[k]).all()
             assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(1.0, np.abs(b[k]).max()), (B, F, k)
+            assert np.array_equal(b[k], c[k]), (B, F, k)
     monkeypatch.delenv('WN_NO_PAIR', raising=False)
+    monkeypatch.delenv('WN_NO_HEADFUSE', raising=False)
     eng.close()
 
 
