@@ -46,18 +46,22 @@ def pmc_traffic(B, F, precision='f16x3', hoisted=False):
     (profiles/r01_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
     PMC counters cannot be collected from inside this process, so this is the value of the
     profiled run of the SAME command; None when the workload differs from a profiled one."""
-    name, kernel = (('r01_pmc_summary.json', 'iaf_layer_kernel') if precision == 'f32' else
-                    ('r01_pmc_summary_f16x3_batch8_hoisted.json', 'iaf_layer_c_kernel') if hoisted else
-                    ('r01_pmc_summary_f16x3.json', 'iaf_layer_h_kernel'))
-    try:
-        with open(os.path.join(ROOT, 'profiles', name)) as f:
-            d = json.load(f)
-        w = d['workload']
-        if (w['batch_per_gpu'], w['frames']) != (B, F):
-            return None
-        return d['kernels'][kernel]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    if precision == 'f32':
+        names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
+    elif hoisted:
+        names, kernel = ['r01_pmc_summary_f16x3.json', 'r01_pmc_summary_f16x3_batch8.json'], 'iaf_layer_c_kernel'
+    else:
+        names, kernel = ['r01_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                d = json.load(f)
+            w = d['workload']
+            if (w['batch_per_gpu'], w['frames']) == (B, F):
+                return d['kernels'][kernel]['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
 
 
 def cpu_baseline(hp_dict, frames, budget_s=25.0):

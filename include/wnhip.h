@@ -97,8 +97,9 @@ typedef struct wn_config {
     int32_t precision;                      /* IAF / upsampler contractions: 0 split-fp16 x3 on the
                                                fp16 MFMA (default), 1 fp32 MFMA */
     int32_t cond_mode;                      /* where the split-fp16 path evaluates the per-layer
-                                               conditioning 1x1s: 0 chosen per call from batch x length,
-                                               1 inside every layer kernel, 2 one GEMM per deconv stack */
+                                               conditioning 1x1s: 0 default (= 2 unless the
+                                               environment says WN_COND=fused), 1 inside every layer
+                                               kernel, 2 one GEMM per deconv stack */
     int32_t use_resize_conv;                /* upsampler = nearest-neighbour resize + SAME conv
                                                (masked.py:294-322) instead of transposed conv;
                                                variables <prefix>resize_conv_i/{W,biases} */
@@ -218,7 +219,9 @@ int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, int B, 
                        float* out_params, void* ws, size_t ws_bytes, void* stream);
 
 /* 1 when wn_iaf_generate(B, F) evaluates the per-layer conditioning 1x1s in one hoisted GEMM per
- * deconv stack (the layer kernels then stream 768 B/sample instead of 1536), else 0. */
+ * deconv stack (the default of the split-fp16 path: the layer kernels then stream 768 B/sample
+ * instead of 1536 and the small-dilation layers run two per launch), 0 for cond_mode 1 (fused)
+ * and for the fp32 path. */
 int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
 /* Measurement aid used by bench.py (not part of the reference's surface, not

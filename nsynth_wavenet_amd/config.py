@@ -62,10 +62,10 @@ PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), '
 
 def default_precision():
     """IAF contraction arithmetic: 'f16x3' = split-fp16 operands on the fp16 MFMA (three MFMAs per
-    product, ~22-bit operands, fp32 accumulate) -- the default; it evaluates the per-layer
-    conditioning 1x1s inside every layer kernel for small batches and hoists them into one GEMM
-    per deconv stack once batch x length outgrows the Infinity Cache ('f16x3-fused' /
-    'f16x3-hoisted' force either form); 'f32' = fp32 MFMA."""
+    product, ~22-bit operands, fp32 accumulate) -- the default; it hoists the per-layer
+    conditioning 1x1s into one GEMM per deconv stack and runs the small-dilation layers two per
+    launch ('f16x3-hoisted' names that form explicitly; 'f16x3-fused' evaluates the 1x1s inside
+    every layer kernel instead and needs no conditioning workspace); 'f32' = fp32 MFMA."""
     import os
     return os.environ.get('WN_PRECISION', 'f16x3')
 

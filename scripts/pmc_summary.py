@@ -1,10 +1,13 @@
-"""Build profiles/r01_pmc_summary_f16x3.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
-    python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json
-Kernels are keyed by their base name; the layer kernel variant with the fused start conv is kept under
-its own key ("iaf_layer_h_kernel<first>")."""
+"""Build a profiles/r01_pmc_summary_*.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
+    python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json [batch_per_gpu] [bench args]
+Kernels are keyed by their base name; variants that do different work per launch keep their own key
+("iaf_layer_h_kernel<first>": start conv fused in; "iaf_layer_c_kernel<head>": flow head in the epilogue;
+"iaf_pair_c_kernel<...>": per template arguments)."""
 import collections, csv, glob, json, os, re, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+extra = sys.argv[4] if len(sys.argv) > 4 else ''
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 
@@ -16,6 +19,10 @@ def key_of(name):
     base, targs = m.group(1), m.group(2) or ''
     if base == 'iaf_layer_h_kernel' and 'true' in targs:
         return base + '<first>'
+    if base == 'iaf_layer_c_kernel' and 'true' in targs:
+        return base + '<head>'
+    if base == 'iaf_pair_c_kernel':
+        return base + targs.replace(' ', '')
     if base in ('deconv_mfma_h_kernel', 'deconv_mfma_hs_kernel'):
         return base + targs.replace(' ', '')
     return base
@@ -37,13 +44,12 @@ for k, d in agg.items():
     kernels[k] = e
 out = {
     '_about': 'rocprofv3 --pmc passes (scripts/pmc_layer.sh: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass, instruction-mix '
-              'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1`, one MI355X, round 1, split-fp16 (f16x3) '
-              'path, config 2 (B=1, F=384, T=76800). Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
+              'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ' + extra + '`, one MI355X, '
+              'round 1, split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
               'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a coalesced '
               'stream, MI355X_MICROARCH.md; calibrated on iaf_head_h_kernel: it reads 98.3 MB exactly once and reports '
-              '~48.8 MB). The working set (enc 78.6 MB + l 2x19.9 MB + weights) fits the 256 MB Infinity Cache, whose hits '
-              'these fabric-side counters include.',
-    'workload': {'batch_per_gpu': 1, 'frames': 384, 'samples': 76800},
+              '~48.8 MB). These fabric-side counters include Infinity Cache hits.',
+    'workload': {'batch_per_gpu': batch, 'frames': 384, 'samples': 76800},
     'kernels': kernels,
 }
 json.dump(out, open(dst, 'w'), indent=1)
