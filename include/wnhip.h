@@ -98,7 +98,8 @@ typedef struct wn_config {
                                                fp16 MFMA (default), 1 fp32 MFMA */
     int32_t cond_mode;                      /* where the split-fp16 path evaluates the per-layer
                                                conditioning 1x1s: 0 default (= 2 unless the
-                                               environment says WN_COND=fused), 1 inside every layer
+                                               environment says WN_COND=fused or the projected term
+                                               of the call would exceed 96 GB), 1 inside every layer
                                                kernel, 2 one GEMM per deconv stack */
     int32_t use_resize_conv;                /* upsampler = nearest-neighbour resize + SAME conv
                                                (masked.py:294-322) instead of transposed conv;

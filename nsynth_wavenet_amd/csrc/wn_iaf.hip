@@ -761,12 +761,18 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 // workspace).  Measured on MI355X (M samples/s, hoisted / fused): 50.7 / 46.8 at one utterance of
 // 4.8 s, 56 / 49 at two, 61 / 42 at eight.
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
-    (void)B; (void)T;
     if (h->cfg.precision != WN_PREC_F16X3 || h->cfg.cond_mode == WN_COND_FUSED) return false;
     if (h->cfg.cond_mode == WN_COND_HOISTED) return true;
     const char* e = getenv("WN_COND");
     if (e && !strcmp(e, "fused")) return false;
-    return true;
+    // the projected term costs 256 B per sample and row block; past a third of the 288 GB of HBM the call
+    // falls back to the fused form, which needs no such workspace
+    int rows = h->cond_rows;
+    if (!h->cfg.share_deconv) {
+        rows = 0;
+        for (const IafFlowPack& fp : h->flows) rows = std::max(rows, (int)fp.layers.size() + 1);
+    }
+    return (double)B * (double)T * 256.0 * rows <= 96e9;
 }
 
 extern "C" int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F) {

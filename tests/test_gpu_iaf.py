@@ -288,6 +288,8 @@ def test_conditioning_placement_policy():
     w = O.synth_weights(hp, 'student', seed=1234, init='tf')
     auto, fused, hoisted = (_engine(cfgd, w, p) for p in ('f16x3', 'f16x3-fused', 'f16x3-hoisted'))
     assert auto.iaf_cond_hoisted(1, 384) and auto.iaf_cond_hoisted(8, 384)
+    # 96 GB of projected conditioning is the limit of the default form (16 KB per sample here)
+    assert auto.iaf_cond_hoisted(64, 384) and not auto.iaf_cond_hoisted(128, 384) and hoisted.iaf_cond_hoisted(128, 384)
     assert not fused.iaf_cond_hoisted(8, 384) and hoisted.iaf_cond_hoisted(1, 8)
     rs = np.random.RandomState(9)
     mel = rs.uniform(0, 1, [3, 80, 80]).astype(np.float32)           # T = 15872 per row
