@@ -99,7 +99,7 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
     if (c.precision != WN_PREC_F16X3 && c.precision != WN_PREC_F32)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
-    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_HOISTED)
+    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_PIPE)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)

@@ -419,6 +419,10 @@ struct IafLayout {
     int XR, c0;
     size_t enc, lA, lB, x, x0, M, S, C, scratch, total;   // byte offsets
     int64_t c_bstride;                                    // floats of hoisted conditioning per batch row
+    // flow pipeline (wn_iaf_p.hip): lA = the n_layers write-once buffers of one batch chunk, enc = one image
+    // per deconv stack, x = X[0 .. n_flows], M / S = one array per flow, cnt = progress words
+    int form, pipe_chunk, pipe_layers, pipe_stacks;
+    size_t cnt, enc_stack_floats;
 };
 
 IafLayout iaf_layout(const wn_handle* h, int B, int F) {
@@ -430,6 +434,29 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F) {
     L.XR = (int)(IAF_XP + L.T);
     size_t o = 0;
     auto carve = [&](size_t floats) { size_t r = o; o += align_up(floats * sizeof(float), 256); return r; };
+    L.form = wn_iaf_form(h, B, L.T);
+    L.pipe_chunk = L.pipe_layers = L.pipe_stacks = 0;
+    L.cnt = L.enc_stack_floats = 0;
+    if (L.form == WN_COND_PIPE && L.T > 0) {
+        for (const IafFlowPack& fp : h->flows) L.pipe_layers += (int)fp.layers.size();
+        L.pipe_stacks = h->cfg.share_deconv ? 1 : h->cfg.n_flows;
+        L.pipe_chunk = wn_iaf_p_chunk(h, B, L.T);
+        L.enc_stack_floats = align_up((size_t)B * IAF_CD * L.TE + 64, 64);
+        L.enc = carve(L.enc_stack_floats * L.pipe_stacks);
+        L.lA = carve((size_t)L.pipe_layers * L.pipe_chunk * IAF_W * L.RS);
+        L.lB = L.lA;
+        L.x = carve((size_t)(h->cfg.n_flows + 1) * B * L.XR);
+        L.x0 = carve((size_t)B * L.T);
+        L.M = carve((size_t)h->cfg.n_flows * B * L.T);
+        L.S = carve((size_t)h->cfg.n_flows * B * L.T);
+        L.cnt = carve((size_t)h->pipe_stages * 64 + 64);
+        L.c_bstride = 0;
+        L.C = o;
+        L.scratch = o;
+        o += wn_deconv_scratch_bytes(h, B, F);
+        L.total = o;
+        return L;
+    }
     L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
     L.lA = carve((size_t)B * IAF_W * L.RS);
     L.lB = carve((size_t)B * IAF_W * L.RS);
@@ -437,7 +464,7 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F) {
     L.x0 = carve((size_t)B * L.T);
     L.M = carve((size_t)B * L.T);
     L.S = carve((size_t)B * L.T);
-    const bool hoist = wn_iaf_hoisted(h, B, L.T);
+    const bool hoist = L.form == WN_COND_HOISTED;
     L.c_bstride = hoist ? (int64_t)wn_iaf_c_floats(h->cfg.share_deconv ? h->cond_rows : 0, L.T) : 0;
     if (hoist && !h->cfg.share_deconv) {        // private deconv stacks: one flow's rows at a time
         int mx = 0;
@@ -558,6 +585,87 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
+// The flow-pipeline form of a generate call (wn_iaf_p.hip): upsampler(s), then every layer and head of
+// every flow in ONE persistent launch per batch chunk, then the final affine + quantiser.
+static int iaf_generate_pipe(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
+                             uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
+                             float* scale_tot, float* rand_out, char* base, hipStream_t st) {
+    const wn_config& c = h->cfg;
+    float* enc = reinterpret_cast<float*>(base + L.enc);
+    unsigned* lbuf = reinterpret_cast<unsigned*>(base + L.lA);
+    float* X = reinterpret_cast<float*>(base + L.x);
+    float* x0g = reinterpret_cast<float*>(base + L.x0);
+    float* M = reinterpret_cast<float*>(base + L.M);
+    float* S = reinterpret_cast<float*>(base + L.S);
+    unsigned* cnt = reinterpret_cast<unsigned*>(base + L.cnt);
+    void* scratch = base + L.scratch;
+    const size_t x_floats = (size_t)B * L.XR, ms_floats = (size_t)B * L.T;
+    // flow inputs: zero everything once (left pads of all n_flows + 1 arrays), then the noise into X[0]
+    WN_HIP(h, hipMemsetAsync(X, 0, (size_t)(c.n_flows + 1) * x_floats * sizeof(float), st));
+    const float* x0 = noise;
+    {
+        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+        if (noise) {
+            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, X, L.T, L.XR);
+        } else {
+            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, X, L.T, L.XR, seed,
+                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
+            x0 = x0g;
+        }
+    }
+    wn_iaf_p_zero_pads(lbuf, L.RS, L.pipe_layers * L.pipe_chunk * 16, st);
+    for (int s = 0; s < L.pipe_stacks; ++s) {
+        const int si = c.share_deconv ? 0 : h->flows[s].deconv_stack;
+        int rc = wn_run_deconv(h, si, mel, B, F, enc + (size_t)s * L.enc_stack_floats, L.TE, scratch, st, true);
+        if (rc) return rc;
+    }
+    WnPipeBufs P;
+    P.lbuf = lbuf;
+    P.enc = reinterpret_cast<const unsigned*>(enc);
+    P.enc_words = (long long)L.enc_stack_floats;
+    P.X = X;
+    P.x_floats = (long long)x_floats;
+    P.M = M;
+    P.S = S;
+    P.ms_floats = (long long)ms_floats;
+    P.cnt = cnt;
+    P.RS = L.RS;
+    P.TE = L.TE;
+    P.T = L.T;
+    P.c0 = L.c0;
+    P.XR = L.XR;
+    if (h->prof_on) {
+        hipEvent_t ev;
+        WN_HIP(h, hipEventCreate(&ev));
+        h->prof_events.push_back(ev);
+        WN_HIP(h, hipEventRecord(ev, st));
+    }
+    for (int b0 = 0; b0 < B; b0 += L.pipe_chunk) {
+        int rc = wn_iaf_p_run(h, P, b0, std::min(L.pipe_chunk, B - b0), st);
+        if (rc) return rc;
+        if (h->prof_on) ++h->prof_launches;
+    }
+    if (h->prof_on) {
+        hipEvent_t ev;
+        WN_HIP(h, hipEventCreate(&ev));
+        h->prof_events.push_back(ev);
+        WN_HIP(h, hipEventRecord(ev, st));
+    }
+    {
+        const int64_t nn = (int64_t)B * L.T;
+        const int Q = c.use_mu_law ? 256 : 65536;
+        const float* Ml = M + (size_t)(c.n_flows - 1) * ms_floats;
+        const float* Sl = S + (size_t)(c.n_flows - 1) * ms_floats;
+        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Ml, Sl, nn,
+                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
+        wn_iaf_p_poison(cnt + (size_t)h->pipe_stages * 64, wav, nn, st);
+        if (rand_out && rand_out != x0)
+            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
 extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, const float* noise,
                                uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
                                float* scale_tot, float* rand_out, void* ws, size_t ws_bytes, void* stream) {
@@ -594,6 +702,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         if (rc) return rc;
         rc = wn_iaf_c_set_attrs(h);
         if (rc) return rc;
+        rc = wn_iaf_p_set_attrs(h);
+        if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_LAYER_FLOATS * sizeof(float)));
@@ -602,6 +712,9 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                                       IAF_HEAD_FLOATS * sizeof(float)));
         h->iaf_attrs_set = true;
     }
+
+    if (L.form == WN_COND_PIPE)
+        return iaf_generate_pipe(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
 
     // zero left pads
     {
@@ -624,7 +737,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
             x0 = x0g;
         }
     }
-    const bool hoist = wn_iaf_hoisted(h, B, L.T);
+    const bool hoist = L.form == WN_COND_HOISTED;
     const unsigned* cond_tab = reinterpret_cast<const unsigned*>(h->d_blob + h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
     if (c.share_deconv) {
@@ -760,11 +873,27 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 // (cond_mode / WN_COND=fused): every layer kernel streams enc itself (1536 B/sample/layer, no extra
 // workspace).  Measured on MI355X (M samples/s, hoisted / fused): 50.7 / 46.8 at one utterance of
 // 4.8 s, 56 / 49 at two, 61 / 42 at eight.
+int wn_iaf_form(const wn_handle* h, int B, int64_t T) {
+    if (h->cfg.precision != WN_PREC_F16X3) return WN_COND_FUSED;
+    int mode = h->cfg.cond_mode;
+    if (mode == WN_COND_AUTO) {
+        const char* e = getenv("WN_COND");
+        if (e && !strcmp(e, "fused")) mode = WN_COND_FUSED;
+        else if (e && !strcmp(e, "hoisted")) mode = WN_COND_HOISTED;
+        else if (e && !strcmp(e, "pipe")) mode = WN_COND_PIPE;
+    }
+    if (mode == WN_COND_PIPE) return wn_iaf_p_supported(h) ? WN_COND_PIPE : WN_COND_FUSED;
+    if (mode == WN_COND_FUSED) return WN_COND_FUSED;
+    if (mode == WN_COND_HOISTED) return WN_COND_HOISTED;
+    return wn_iaf_hoisted(h, B, T) ? WN_COND_HOISTED : WN_COND_FUSED;
+}
+
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
     if (h->cfg.precision != WN_PREC_F16X3 || h->cfg.cond_mode == WN_COND_FUSED) return false;
     if (h->cfg.cond_mode == WN_COND_HOISTED) return true;
+    if (h->cfg.cond_mode == WN_COND_PIPE) return false;
     const char* e = getenv("WN_COND");
-    if (e && !strcmp(e, "fused")) return false;
+    if (e && (!strcmp(e, "fused") || !strcmp(e, "pipe"))) return false;
     // the projected term costs 256 B per sample and row block; past a third of the 288 GB of HBM the call
     // falls back to the fused form, which needs no such workspace
     int rows = h->cond_rows;
@@ -777,7 +906,7 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 
 extern "C" int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F) {
     if (!h || h->cfg.kind != WN_KIND_STUDENT || B < 1 || F < 1) return 0;
-    return wn_iaf_hoisted(h, B, wn_iaf_length(h, F)) ? 1 : 0;
+    return wn_iaf_form(h, B, wn_iaf_length(h, F)) == WN_COND_HOISTED ? 1 : 0;
 }
 
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F) { return iaf_layout(h, B, F).total; }

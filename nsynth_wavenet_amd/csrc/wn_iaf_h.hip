@@ -472,6 +472,16 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
         blob.resize(blob.size() + align_up(tab.size(), 4));
         memcpy(blob.data() + h->cond_tab_off, tab.data(), tab.size() * sizeof(unsigned));
     }
+    // stage table of the flow pipeline (wn_iaf_p.hip)
+    {
+        std::vector<int> tab;
+        wn_iaf_p_stage_table(h, tab);
+        blob.resize(align_up(blob.size(), 64));
+        h->pipe_tab_off = blob.size();
+        h->pipe_stages = (int)(tab.size() / 8);
+        blob.resize(blob.size() + align_up(tab.size(), 4));
+        memcpy(blob.data() + h->pipe_tab_off, tab.data(), tab.size() * sizeof(int));
+    }
     return WN_OK;
 }
 

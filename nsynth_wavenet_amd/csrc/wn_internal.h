@@ -109,6 +109,9 @@ struct wn_handle {
     // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
     size_t cond_tab_off = 0;
     int cond_rows = 0;
+    // flow pipeline (wn_iaf_p.hip): stage table (8 ints per stage) inside the blob
+    size_t pipe_tab_off = 0;
+    int pipe_stages = 0;
     int frame_shift = 1;
     int num_cu = 256;
     mutable std::string err;
@@ -149,6 +152,7 @@ constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
 constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB Infinity Cache, else fused
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
+constexpr int WN_COND_PIPE = 3;    // fused form, all layers and heads as ONE persistent pipeline launch (wn_iaf_p.hip)
 
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
@@ -195,6 +199,28 @@ void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* 
                    const float* x, int XR, const float* wstart);
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
                    float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
+// ---- flow pipeline (wn_iaf_p.hip) ----
+struct WnPipeBufs {
+    unsigned* lbuf;            // n_layers write-once activation buffers of one batch chunk
+    const unsigned* enc;       // [stack][B][256 x TE] G4 words
+    long long enc_words;       //   words per stack
+    float* X;                  // [n_flows + 1][B][XR]
+    long long x_floats;
+    float* M;                  // [n_flows][B][T]
+    float* S;
+    long long ms_floats;
+    unsigned* cnt;             // progress words + error word
+    int64_t RS, TE, T;
+    int c0, XR;
+};
+void wn_iaf_p_stage_table(const wn_handle* h, std::vector<int>& tab);
+bool wn_iaf_p_supported(const wn_handle* h);
+int wn_iaf_p_set_attrs(wn_handle* h);
+int wn_iaf_p_chunk(const wn_handle* h, int B, int64_t T);
+int wn_iaf_p_run(wn_handle* h, const WnPipeBufs& P, int B0, int Bc, hipStream_t st);
+void wn_iaf_p_zero_pads(unsigned* lbuf, int64_t RS, int rows, hipStream_t st);
+void wn_iaf_p_poison(const unsigned* err, float* wav, int64_t n, hipStream_t st);
+int wn_iaf_form(const wn_handle* h, int B, int64_t T);   // WN_COND_FUSED / _HOISTED / _PIPE for this call
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);

@@ -10,11 +10,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d $OUT/inst -o inst -- $CMD > $OUT/inst.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -o tcc -- $CMD > $OUT/tcc.log 2>&1
 ls -R $OUT | head -30
 python - <<PY
 import csv, glob, collections, os
 out = "$OUT"
-for sub in ("sq", "fetch", "write", "inst"):
+for sub in ("sq", "fetch", "write", "inst", "tcc"):
     files = glob.glob(os.path.join(out, sub, "*counter_collection.csv"))
     if not files:
         print(sub, "no counter file"); continue
@@ -24,6 +25,6 @@ for sub in ("sq", "fetch", "write", "inst"):
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
         cnt[(k, row["Counter_Name"])] += 1
     for k in agg:
-        if "iaf_layer" in k or "deconv_mfma" in k or "iaf_head" in k:
+        if "iaf_layer" in k or "deconv_mfma" in k or "iaf_head" in k or "iaf_pipe" in k or "iaf_cond" in k or "iaf_pair" in k:
             print(sub, k, {c: round(v / cnt[(k, c)], 1) for c, v in agg[k].items()}, "dispatches", max(cnt[(k, c)] for c in agg[k]))
 PY
