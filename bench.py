@@ -3,18 +3,23 @@ generation on MI355X -- BASELINE.json's metric on its configs[1]
 ("parallel_wavenet.json IAF student gen, 1 MI355X, batch=1 synthetic 80-dim mel").
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the whole generation hot path (noise draw, mel upsampler, 4 IAF
-flows = 60 fused residual-layer kernels + 4 heads, clip/quantise) over one batch of
-synthetic mels already resident in HBM.  Utterances are independent, so N ranks each
-generate their own batch with no data-path collective (weak scaling); the only
-communication is the one-time weight broadcast from rank 0 (untimed).
-Rank 0 prints ONE JSON line.
+With N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`);
+started under torch.distributed.run it uses the ranks it is given.  One process per GPU, RCCL.
+
+A step = one pass of the whole generation hot path (noise draw, mel upsampler, conditioning GEMM,
+4 IAF flows = 60 residual layers + 4 heads, clip/quantise) over one batch of synthetic mels already
+resident in HBM.  Utterances are independent, so N ranks each generate their own batch with no
+data-path collective (weak scaling); the only communication is the one-time weight broadcast from
+rank 0 (untimed).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,10 +30,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from nsynth_wavenet_amd import build as wbuild           # noqa: E402
 from nsynth_wavenet_amd import config as cfg            # noqa: E402
 from nsynth_wavenet_amd import dist as wdist             # noqa: E402
 from nsynth_wavenet_amd import weights as wts            # noqa: E402
-from nsynth_wavenet_amd.engine import Engine             # noqa: E402
 
 # per generated sample (BASELINE.md section 2 / SURVEY section 8d)
 LAYER_FLOP_PER_SAMPLE = 61440          # one residual layer: 2 * (12288 + 16384 + 2048) MAC
@@ -43,21 +48,24 @@ PEAK_HBM_GBPS = 8000.0
 
 def pmc_traffic(B, F, precision='f16x3', hoisted=False):
     """HBM bytes per launch of the dominant layer kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
-    PMC counters cannot be collected from inside this process, so this is the value of the
-    profiled run of the SAME command; None when the workload differs from a profiled one."""
+    (profiles/r0*_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
+    PMC counters cannot be collected from inside this process, so this is the value of the profiled
+    run of the SAME command -- and only when that profile was taken from the kernel sources this
+    process runs: a summary carries the hash of csrc/ + include/ (build.source_hash) it was measured
+    on; a summary without a hash, or with another one, is stale and gives None."""
     if precision == 'f32':
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
     elif hoisted:
-        names, kernel = ['r01_pmc_summary_f16x3.json', 'r01_pmc_summary_f16x3_batch8.json'], 'iaf_layer_c_kernel'
+        names, kernel = ['r02_pmc_summary_f16x3.json', 'r02_pmc_summary_f16x3_batch8.json'], 'iaf_layer_c_kernel'
     else:
-        names, kernel = ['r01_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
+        names, kernel = ['r02_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
+    have = wbuild.source_hash()
     for name in names:
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f)
             w = d['workload']
-            if (w['batch_per_gpu'], w['frames']) == (B, F):
+            if (w['batch_per_gpu'], w['frames']) == (B, F) and d.get('source_hash') == have:
                 return d['kernels'][kernel]['hbm_bytes_per_launch']
         except (OSError, KeyError, ValueError):
             pass
@@ -109,6 +117,144 @@ def cpu_baseline(hp_dict, frames, budget_s=25.0):
             'x_realtime': T / med / 16000.0}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a rendezvous in the environment: run N ranks of this script
+    on this node under torch.distributed.run and pass their output (rank 0's JSON line) through."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every):
+    """W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
+    def step(i):
+        return eng.iaf_generate(mel, None, seed=1000 * rank + i, want=('wav',))['wav']
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local])
+            torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    wav = None
+    for i in range(steps):
+        # the event pairs around the layer kernels cost the stream a bubble each: sample them
+        eng.profile_pause(i % max(events_every, 1) != 0)
+        wav = step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    layer_ms, layer_launches = eng.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, layer_ms, layer_launches, wav
+
+
+def roofline_of(eng, B, F, T, layer_ms, layer_launches):
+    """Roofline record of the dominant kernel (the single-layer launches bracketed by HIP events inside the
+    library, on the stream they are launched on)."""
+    avg_layer_s = layer_ms * 1e-3 / max(layer_launches, 1)
+    flops_per_launch = LAYER_FLOP_PER_SAMPLE * B * T
+    bytes_per_launch = LAYER_BYTES_PER_SAMPLE * B * T
+    achieved_tf = flops_per_launch / avg_layer_s / 1e12
+    achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+    hoisted = eng.iaf_cond_hoisted(B, F)
+    if hoisted:
+        # conditioning 1x1s hoisted into one GEMM per deconv stack (the default): the layer
+        # kernel streams l in/out and the projected term, 768 B/sample; the event pairs bracket the
+        # single-layer launches only (36 of the 60 layers; the other 24 run two per launch)
+        bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        roof = {'kernel': 'iaf_layer_c_kernel (dilated conv + gate + residual 1x1 on hoisted conditioning, split-fp16 MFMA)',
+                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'note': '768 B/sample/layer in this kernel + 256 B/sample/layer written by iaf_cond_h_kernel '
+                        '(vs 1536 B/sample/layer of the fused layer kernel)'}
+    elif eng.precision == 'f16x3-pipe':
+        # ONE launch = every layer and head of the student; the fused form's bytes (SURVEY 8d: 1536 B per
+        # sample and layer + 1296 B per head) over the launch time
+        nl = sum(eng.hp.num_iaf_layers)
+        nh = len(eng.hp.num_iaf_layers)
+        bytes_per_launch = (LAYER_BYTES_PER_SAMPLE * nl + 1296 * nh) * B * T
+        flops_per_launch = (LAYER_FLOP_PER_SAMPLE * nl + 41600 * nh) * B * T
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        achieved_tf = flops_per_launch / avg_layer_s / 1e12
+        roof = {'kernel': 'iaf_pipe_kernel (all residual layers and heads, one persistent launch, split-fp16 MFMA)',
+                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS}}
+    elif eng.precision.startswith('f16x3'):
+        # split-fp16 operands on the fp16 MFMA: 3 MFMAs per product -> the matrix pipe needs
+        # 3*61440 fp16-FLOP/sample at a 2.5 PFLOP/s peak (0.07 ns) vs 1536 B/sample at 8 TB/s
+        # (0.19 ns): the kernel is HBM-bound
+        roof = {'kernel': 'iaf_layer_h_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, split-fp16 MFMA)',
+                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS,
+                              'algorithmic_TFLOPs': achieved_tf}}
+    else:
+        roof = {'kernel': 'iaf_layer_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, fp32 MFMA)',
+                'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
+    roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted),
+                 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass of this command on these kernel sources, '
+                                 'profiles/; null when no such pass is committed)',
+                 'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
+                 'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
+    return roof
+
+
+def stub_main(args, rank, world, local):
+    """--stub: the launcher / rendezvous / timing protocol with a torch-CPU step and the gloo backend
+    (exercised by tests/test_dist.py on machines without a GPU).  Not a measurement."""
+    if world > 1:
+        wdist.init_process_group('gloo')
+    x = torch.ones(64, 64)
+    for _ in range(args.warmup):
+        x = torch.tanh(x @ x * 1e-2)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = torch.tanh(x @ x * 1e-2)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = world
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ws = torch.ones(1)
+        dist.all_reduce(ws)
+        seen = int(ws.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'stub', 'value': args.steps * world / elapsed, 'unit': 'steps/s', 'n_gpus': world,
+                          'world_size_seen': seen, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': elapsed / args.steps * 1e3, 'data': 'stub'}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -118,18 +264,23 @@ def main():
     ap.add_argument('--frames', type=int, default=384, help='mel frames per utterance (384 -> 76800 samples = 4.8 s)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the second roofline block (8 utterances per GPU) and the PCIe-inclusive timing')
     ap.add_argument('--layer-events-every', type=int, default=4,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
+    ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank, world, local = wdist.env_rank_world()
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if world != args.gpus:
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
-                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus {} ...'.format(args.gpus, args.gpus))
+    if args.stub:
+        return stub_main(args, rank, world, local)
+    from nsynth_wavenet_amd.engine import Engine
     torch.cuda.set_device(local)
     if world > 1:
         wdist.init_process_group('nccl')
@@ -146,82 +297,24 @@ def main():
 
     B, F = args.batch_per_gpu, args.frames
     T = eng.iaf_length(F)
-    mel = torch.from_numpy(np.random.RandomState(12345 + rank).uniform(0, 1, [B, F, 80]).astype(np.float32)).to(dev)
-
-    def step(i):
-        return eng.iaf_generate(mel, None, seed=1000 * rank + i, want=('wav',))['wav']
-
-    for i in range(args.warmup):
-        step(i)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier(device_ids=[local])
-            torch.cuda.synchronize(dev)
-
-    fence()
-    eng.profile_begin()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # the event pairs around the layer kernels cost the stream a bubble each: sample them
-        eng.profile_pause(i % max(args.layer_events_every, 1) != 0)
-        wav = step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    layer_ms, layer_launches = eng.profile_end()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    mel_host = np.random.RandomState(12345 + rank).uniform(0, 1, [B, F, 80]).astype(np.float32)
+    mel = torch.from_numpy(mel_host).to(dev)
+    elapsed, layer_ms, layer_launches, wav = measure(eng, mel, args.steps, args.warmup, rank, world, local, dev,
+                                                     args.layer_events_every)
     assert wav.shape == (B, T) and bool(torch.isfinite(wav).all())
 
     if rank == 0:
         total_samples = world * B * T * args.steps
         value = total_samples / elapsed
-        avg_layer_s = layer_ms * 1e-3 / max(layer_launches, 1)
-        flops_per_launch = LAYER_FLOP_PER_SAMPLE * B * T
-        bytes_per_launch = LAYER_BYTES_PER_SAMPLE * B * T
-        achieved_tf = flops_per_launch / avg_layer_s / 1e12
-        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
-        hoisted = eng.iaf_cond_hoisted(B, F)
-        if hoisted:
-            # conditioning 1x1s hoisted into one GEMM per deconv stack (the default): the layer
-            # kernel streams l in/out and the projected term, 768 B/sample; the event pairs bracket the
-            # single-layer launches only (36 of the 60 layers; the other 24 run two per launch)
-            bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
-            achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
-            roof = {'kernel': 'iaf_layer_c_kernel (dilated conv + gate + residual 1x1 on hoisted conditioning, split-fp16 MFMA)',
-                    'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                    'frac': achieved_gbps / PEAK_HBM_GBPS,
-                    'note': '768 B/sample/layer in this kernel + 256 B/sample/layer written by iaf_cond_h_kernel '
-                            '(vs 1536 B/sample/layer of the fused layer kernel)'}
-            dtype = 'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
-        elif eng.precision.startswith('f16x3'):
-            # split-fp16 operands on the fp16 MFMA: 3 MFMAs per product -> the matrix pipe needs
-            # 3*61440 fp16-FLOP/sample at a 2.5 PFLOP/s peak (0.07 ns) vs 1536 B/sample at 8 TB/s
-            # (0.19 ns): the kernel is HBM-bound
-            roof = {'kernel': 'iaf_layer_h_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, split-fp16 MFMA)',
-                    'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                    'frac': achieved_gbps / PEAK_HBM_GBPS,
-                    'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS,
-                                  'algorithmic_TFLOPs': achieved_tf}}
-            dtype = 'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
-        else:
-            roof = {'kernel': 'iaf_layer_kernel (fused dilated conv + cond 1x1 + gate + residual 1x1, fp32 MFMA)',
-                    'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                    'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
-            dtype = 'f32'
-        roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted),
-                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
-                     'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
-                     'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
+        roof = roofline_of(eng, B, F, T, layer_ms, layer_launches)
+        dtype = 'f32' if eng.precision == 'f32' else \
+            'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
         rec = {
             'metric': '16 kHz audio samples/sec, parallel-WaveNet (IAF student) generation',
             'value': value,
             'unit': 'samples/s',
             'n_gpus': world,
+            'world_size_seen': dist.get_world_size() if world > 1 else 1,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
@@ -246,6 +339,30 @@ def main():
             },
             'roofline': roof,
         }
+    if world == 1 and not args.no_extras:
+        # (1) PCIe-inclusive call: pageable numpy mel in -> H2D -> generate -> D2H -> numpy wav out, the
+        #     path of parallelgen.synthesis.  Reported beside the resident figure, never as `value`.
+        n_e2e = max(3, min(args.steps, 20))
+        for i in range(2):
+            eng.iaf_generate(mel_host, None, seed=i, want=('wav',))['wav'].cpu().numpy()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n_e2e):
+            out = eng.iaf_generate(mel_host, None, seed=7000 + i, want=('wav',))['wav'].cpu().numpy()
+        rec['e2e_ms_per_step'] = (time.perf_counter() - t0) / n_e2e * 1e3
+        rec['e2e_note'] = 'host numpy mel -> H2D -> generate -> D2H -> host numpy wav ({} calls); `value` is the ' \
+                          'HBM-resident rate'.format(n_e2e)
+        assert out.shape == (B, T)
+        # (2) the same dominant kernel with the GPU filled: 8 utterances per GPU (BASELINE configs[2]'s per-GPU share)
+        if B != 8:
+            mel8 = torch.from_numpy(np.random.RandomState(777).uniform(0, 1, [8, F, 80]).astype(np.float32)).to(dev)
+            n8 = max(3, min(args.steps, 20))
+            el8, lms8, ll8, wav8 = measure(eng, mel8, n8, 2, rank, world, local, dev, 2)
+            r8 = roofline_of(eng, 8, F, T, lms8, ll8)
+            r8.update({'batch_per_gpu': 8, 'steps': n8, 'ms_per_step': el8 / n8 * 1e3,
+                       'samples_per_sec': 8 * T * n8 / el8})
+            rec['roofline_b8'] = r8
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(hp_dict, F)
         print(json.dumps(rec), flush=True)

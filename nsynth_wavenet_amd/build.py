@@ -26,13 +26,35 @@ def find_hipcc():
     raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + \
+STAMP_PATH = os.path.join(LIB_DIR, 'libwnhip.sha256')
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + \
            [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def source_hash():
+    """sha256 over the kernel / host sources and headers the library is built from (names + contents,
+    plus the extra compiler flags).  Stored next to the built library; bench.py stamps it into the PMC
+    summaries so that a profile of other sources is never replayed as a measurement."""
+    import hashlib
+    hh = hashlib.sha256()
+    for d in sorted(_deps(), key=os.path.basename):
+        hh.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            hh.update(f.read())
+    hh.update(os.environ.get('WN_EXTRA_FLAGS', '').encode())
+    return hh.hexdigest()
+
+
+def _stale():
+    """The library is current iff it exists and was built from exactly these sources (content hash, not
+    mtimes: a checkout or an rsync does not preserve them)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+        return True
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -64,6 +86,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP_PATH, 'w') as f:
+        f.write(source_hash() + '\n')
     return LIB_PATH
 
 

@@ -390,6 +390,47 @@ def ce_sample(out, quant_chann, u, dtype=np.float32):
     return (k - quant_chann // 2).astype(np.int32)
 
 
+def sample_margin(out, rnd, hp):
+    """Test aid for the integer-parity checks: the sampler of loss_func.py:140-206 evaluated in float64 on
+    given network outputs `out` [B, ow] and randoms `rnd` [B, n_rand], returning
+      idx     the index float64 arithmetic selects,
+      margin  how far the pre-floor() quantity is from the nearest decision boundary -- in index units
+              (x*Q/2 against the integers) for mol / gauss, and as a fraction of the total softmax mass
+              (u*total against the running sums) for ce,
+      gap     mol only: distance between the two largest selection scores (the argmax margin).
+    A float32 implementation may differ from `idx` only by one step and only where `margin` is of the
+    size of its own rounding error."""
+    out = np.asarray(out, np.float64)
+    rnd = np.asarray(rnd, np.float64).reshape(out.shape[0], -1)
+    qc = quant_chann_of(hp)
+    r = np.arange(out.shape[0])
+    if hp.loss_type == 'ce':
+        e = np.exp(out - out.max(axis=1, keepdims=True))
+        cdf = np.cumsum(e, axis=1)
+        thr = rnd[:, 0] * cdf[:, -1]
+        k = np.minimum((cdf <= thr[:, None]).sum(axis=1), out.shape[1] - 1)
+        margin = np.abs(cdf - thr[:, None]).min(axis=1) / cdf[:, -1]
+        return (k - qc // 2).astype(np.int64), margin, None
+    if hp.loss_type == 'mol':
+        M = out.shape[1] // 3
+        sel = out[:, :M] - np.log(-np.log(rnd[:, :M]))
+        k = np.argmax(sel, axis=1)
+        srt = np.sort(sel, axis=1)
+        gap = srt[:, -1] - srt[:, -2] if M > 1 else np.full(out.shape[0], np.inf)
+        ls = np.clip(out[r, 2 * M + k], -7.0, 7.0)
+        u = rnd[:, M]
+        x = out[r, M + k] + np.exp(ls) * (np.log(u) - np.log(1.0 - u))
+    else:
+        gap = None
+        x = out[:, 0] + np.exp(np.maximum(out[:, 1], -7.0)) * rnd[:, 0]
+    x = np.clip(x, -1.0, 1.0 - 2.0 / qc)
+    y = x * (qc / 2.0)
+    margin = np.abs(y - np.round(y))
+    # a clipped value sits exactly on an integer by construction: it cannot flip
+    margin = np.where((x <= -1.0) | (x >= 1.0 - 2.0 / qc), np.inf, margin)
+    return np.floor(y).astype(np.int64), margin, gap
+
+
 # --------------------------------------------------------------------------
 # autoregressive step   (wavenet.py:379-514, masked.py:328-405)
 # --------------------------------------------------------------------------
@@ -500,6 +541,28 @@ def fastgen_synthesis(encoding, rnd, weights, hp, dtype=np.float32, return_out=F
     if return_out:
         return wav, idx, np.stack(outs, axis=1)
     return wav, idx
+
+
+def scale_probe_weights(hp):
+    """Test aid: student weights (one flow, one layer) that make the flow-head scale parameter of sample t
+    equal the flow input of sample t-1 -- so that feeding N(0,1) noise turns `scale_tot` into
+    clip(softplus(N(0,1)), e^-9, e^7), the quantity the reference's tests/test_scale.py:94-107 draws
+    (get_scale, use_log_scale=False).  start_conv copies +x[t-1] / -x[t-1] into channels 0 / 1; the
+    residual layer is zero; out1 is the identity on those channels; out2_scale = ch0 - ch1 = relu(x) - relu(-x)."""
+    assert list(hp.num_iaf_layers) == [1]
+    w = {k: np.zeros_like(v) for k, v in synth_weights(hp, 'student', seed=0).items()}
+    w['iaf_1/start_conv/W'][0, 2, 0, 0] = 1.0       # tap k=2 of shift_right(x) is x[t-1]
+    w['iaf_1/start_conv/W'][0, 2, 0, 1] = -1.0
+    w['iaf_1/out1/W'][0, 0, 0, 0] = 1.0
+    w['iaf_1/out1/W'][0, 0, 1, 1] = 1.0
+    w['iaf_1/out2_scale/W'][0, 0, 0, 0] = 1.0
+    w['iaf_1/out2_scale/W'][0, 0, 1, 0] = -1.0
+    return w
+
+
+# analytic moments of s = softplus(Z), Z ~ N(0,1) (the e^-9 / e^7 clip is beyond 9 sigma): E s, E s^2
+SOFTPLUS_N01_M1 = 0.8060591833474399
+SOFTPLUS_N01_M2 = 0.9212459088593004
 
 
 # --------------------------------------------------------------------------

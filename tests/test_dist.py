@@ -72,3 +72,24 @@ def test_world_size_2_gloo_broadcast_and_gather():
         p.join(60)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no rendezvous in the environment (the command the driver uses) must start
+    its N ranks itself and print ONE JSON line from rank 0.  Driven here with the --stub step (torch-CPU, gloo)
+    so that the launcher, the rendezvous on 127.0.0.1 and the timing protocol run on a machine without GPUs."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--stub'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1
+    # under an existing rendezvous with a mismatching world size the script refuses instead of guessing
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub'], env=env2,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0

@@ -40,18 +40,53 @@ def test_golden_ar(tag):
     Q = 256 if cfgd['use_mu_law'] else 65536
     assert gi.min() >= -Q // 2 and gi.max() < Q // 2
     fg = O.Fastgen(w, hp, B, np.float32)
-    # the sampling head is exact given the engine's own network output ...
+    # Integer parity of the sampling head (loss_func.py:140-206) GIVEN the engine's own network output and
+    # the injected randoms: against float64 arithmetic the index may differ by ONE step, and only where
+    # the pre-floor() quantity sits within float32 rounding of a decision boundary.
     gop = _np(out['out_params'])
+    mol = hp.loss_type == 'mol'
+    n_bad = n_flip = 0
+    for t in range(Tn):
+        i64, margin, gap = O.sample_margin(gop[:, t], g['rnd'][t], hp)
+        d = gi[:, t].astype(np.int64) - i64
+        flip = d != 0
+        n_flip += int(flip.sum())
+        if hp.loss_type == 'ce':
+            ok = (np.abs(d) <= 1) & (~flip | (margin <= 2e-5))     # 256 fp32 running sums: ~1.5e-5 of the mass
+        else:
+            # |x| <= 1 in fp32 -> x*Q/2 carries <= ~4e-3 index units of rounding at Q = 65536 (libm exp/log 1-2 ulp)
+            tol = 0.02 if Q == 65536 else 1e-3
+            ok = (np.abs(d) <= 1) & (~flip | (margin <= tol))
+            if mol:     # a different mixture component only where the two best scores tie within fp32 noise
+                ok |= gap <= 1e-5
+        n_bad += int((~ok).sum())
+    print('{}: sampler index vs float64: {} of {} differ by one step at a boundary, {} unexplained'.format(
+        tag, n_flip, B * Tn, n_bad))
+    assert n_bad == 0
+    assert n_flip <= max(2, B * Tn // 20)
+    # the float32 oracle sampler on the same inputs agrees except at those boundary cases as well
     mism = sum(int((fg.sample_from(gop[:, t], g['rnd'][t]) != gi[:, t]).sum()) for t in range(Tn))
-    assert mism <= max(1, B * Tn // 50)        # <= 1 LSB flips where libm rounding crosses floor()
+    assert mism <= n_flip + max(2, B * Tn // 20)
     # ... the fed-back audio is the de-quantised index ...
     assert np.abs(_np(out['wav']) - fg.dequant(gi)).max() <= 2.0 ** -23
-    # ... and the free-running index stream tracks the oracle loop until float noise forks it
+    # ... and the free-running index stream IS the oracle loop's until the first step at which the engine's
+    # own pre-floor quantity sits at a decision boundary (there float noise may fork the two loops by one step)
     diff = gi != g['free_idx']
     first = int(np.argwhere(diff)[:, 1].min()) if diff.any() else Tn
-    assert first >= min(Tn, 8)
-    if not diff.any():
+    if first < Tn:
+        assert not diff[:, :first].any()
+        rows = np.where(diff[:, first])[0]
+        _, margin, gap = O.sample_margin(gop[:, first], g['rnd'][first], hp)
+        dd = np.abs(gi[rows, first].astype(np.int64) - g['free_idx'][rows, first])
+        lim = 2e-4 if hp.loss_type == 'ce' else (0.25 if Q == 65536 else 5e-3)
+        near = margin[rows] <= lim
+        if mol:
+            near |= gap[rows] <= 1e-4
+        assert np.all(near), (first, margin[rows], dd)
+        assert np.all(dd[margin[rows] <= lim] <= 1)
+    else:
         assert np.abs(_np(out['wav']) - g['free_wav']).max() <= 2.0 ** -23
+    print('{}: free run identical to the oracle loop for {} of {} steps'.format(tag, first, Tn))
     # single-step API, reference test shape: wav [B,1], encoding [B,Cd]
     st = eng.ar_new_state(B)
     fg2 = O.Fastgen(w, hp, B, np.float32)

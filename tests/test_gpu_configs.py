@@ -1,0 +1,162 @@
+"""BASELINE.json configurations that the other GPU tests do not run at their own shape:
+
+  configs[0]  the reference's own CPU-runnable case: the tests/test_data utterance (154 480 samples ->
+              F = 773 mel frames) through fastgen (wavenet_mol.json teacher, 154 600 samples out) and
+              through the parallel student (154 112 samples out, centre crop 244) -- the lengths of the
+              reference's committed output wavs (tests/golden/ref_fixture_facts.npz);
+  configs[4]  parallel_wavenet_gauss.json as shipped (Gaussian head, four PRIVATE deconv stacks), the
+              per-GPU share of 128 utterances over 8 GPUs = 16 utterances of F = 384.
+
+The waveform is synthetic (the reference's test wav is not copied into this repository); everything
+else -- featuriser on the device, upsampler, flows / autoregressive loop, quantiser -- is the product path
+through the C ABI.  Checked: the reference-held facts (lengths, 2^-15 grid, range), the reference's
+invariants K1 / K2, and parity with the CPU restatements where they finish in seconds."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _fixture_shaped_wav():
+    """154 480 samples (the length of tests/test_data/test.wav): a few decaying partials + noise."""
+    rs = np.random.RandomState(2024)
+    n = 154480
+    t = np.arange(n) / 16000.0
+    y = sum(a * np.sin(2 * np.pi * f * t + p) for a, f, p in ((0.30, 180.0, 0.1), (0.20, 410.0, 1.3), (0.10, 2250.0, 2.0)))
+    y = y * (0.6 + 0.4 * np.sin(2 * np.pi * 1.7 * t)) + 0.02 * rs.standard_normal(n)
+    return np.clip(y, -0.99, 0.99).astype(np.float32)[None, :]
+
+
+def test_config0_student_on_the_fixture_shaped_utterance():
+    """wav -> device mel (F = 773) -> IAF: 154 112 samples with centre crop 244 (K4), K2, K5, both execution
+    forms, and parity with the independent torch-CPU implementation on the whole utterance."""
+    import torch
+    from oracle import wavenet_np as O
+    from oracle.torch_ref import StudentRef
+    from nsynth_wavenet_amd.auxilaries import mel_extractor as M
+    from nsynth_wavenet_amd.engine import Engine
+    facts = np.load(os.path.join(GOLD, 'ref_fixture_facts.npz'))
+    wav_in = _fixture_shaped_wav()
+    mel = M.batch_melspectrogram_device(wav_in)
+    assert mel.is_cuda and tuple(mel.shape) == (1, 773, 80)
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    T = 154112
+    assert O.iaf_length(773, hp) == T and (773 * 200 - T) // 2 == 244
+    assert int(facts['test_wav/n']) == wav_in.shape[1]
+    assert int(facts['pred_data-pwn-failed_cases/gen_LJ001-0001-cl.wav/n']) == T     # the reference's own output length
+    noise = O.logistic_from_uniform(np.random.RandomState(12346).uniform(1e-5, 1 - 1e-5, [1, T]))
+    outs = {}
+    for prec in ('f16x3', 'f16x3-fused'):
+        eng = Engine(cfgd, precision=prec).load_weights(w)
+        assert eng.iaf_length(773) == T
+        a = eng.iaf_generate(mel, noise, want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot', 'rand_input'))
+        b = eng.iaf_generate(mel, noise, want=('x',))
+        assert torch.equal(a['x'], b['x'])                                   # deterministic
+        outs[prec] = {k: _np(v) for k, v in a.items()}
+        eng.close()
+    o = outs['f16x3']
+    x, m, s, r = (o[k].astype(np.float64) for k in ('x', 'mean_tot', 'scale_tot', 'rand_input'))
+    assert x.shape == (1, T) and np.all(np.isfinite(x)) and np.all(s > 0)
+    assert np.abs(x - (r * s + m)).max() <= 1e-6 * max(1.0, np.abs(x).max())                         # K2
+    wv = o['wav'].astype(np.float64)
+    assert np.all(wv * 32768 == np.round(wv * 32768)) and wv.min() >= -1 and wv.max() <= 1 - 2.0 ** -15   # K5
+    assert np.array_equal(o['idx'], (wv * 32768).astype(np.int32))
+    scale = max(1.0, np.abs(x).max())
+    assert np.abs(outs['f16x3-fused']['x'] - o['x']).max() <= 2e-6 * scale
+    ref_x = StudentRef(w, hp).feed_forward(_np(mel), noise)['x'].astype(np.float64)   # torch-CPU fp32, whole utterance
+    assert np.abs(o['x'] - ref_x).max() <= 2e-5 * scale
+
+
+def test_config0_fastgen_on_the_fixture_shaped_utterance():
+    """wavenet_mol.json as shipped: wav -> device mel -> fastgen.encode (F*200 = 154 600 conditioning steps),
+    K1 on a 2 048-step prefix (incremental step == full-sequence teacher == float64 oracle), then the free-running
+    loop over ALL 154 600 steps: length, 2^-15 grid and range of the reference's gen_LJ001-0001.wav (K4, K5)."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.auxilaries import mel_extractor as M
+    from nsynth_wavenet_amd.engine import Engine
+    wav_in = _fixture_shaped_wav()
+    mel = M.batch_melspectrogram_device(wav_in)
+    cfgd = load_json('wavenet_mol.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    Tn = eng.ar_length(773)
+    facts = np.load(os.path.join(GOLD, 'ref_fixture_facts.npz'))
+    assert Tn == 154600 == int(facts['pred_data-no_mu_law+mol/gen_LJ001-0001.wav/n'])
+    enc = eng.deconv(mel)
+    assert tuple(enc.shape) == (1, Tn, 256)
+    # K1 on a prefix: conditioning of the first 11 frames, centre-cropped to 2 048 steps like Wavenet.feed_forward
+    P, Fp = 2048, 11
+    left = (Fp * 200 - P) // 2
+    mel_p = mel[:, :Fp]
+    enc_p = _np(eng.deconv(mel_p))[:, left:left + P]
+    forced = wav_in[:, :P]
+    rnd = np.random.RandomState(777).uniform(1e-5, 1 - 1e-5, [P, 1, eng.ar_n_rand()]).astype(np.float32)
+    inc = _np(eng.ar_generate(enc_p, rnd, forced_wav=forced, want_out=True)['out_params'])
+    full = _np(eng.teacher_forward(forced, mel_p))
+    enc_o = O.deconv_stack(_np(mel_p), w, hp, '', np.float64)[:, left:left + P]
+    ref = O.teacher_feed_forward(O.encode_signal(forced, hp, np.float64), enc_o, w, hp, np.float64)
+    sc = max(1.0, np.abs(ref).max())
+    assert np.abs(inc - ref).max() <= 5e-5 * sc and np.abs(full - ref).max() <= 5e-5 * sc
+    # the whole utterance, free running, randoms drawn on the device
+    out = eng.ar_generate(enc, None, seed=3)
+    idx, wv = _np(out['idx']), _np(out['wav']).astype(np.float64)
+    assert idx.shape == (1, Tn) and wv.shape == (1, Tn)
+    assert idx.min() >= -32768 and idx.max() <= 32767
+    assert np.all(wv * 32768 == np.round(wv * 32768)) and wv.min() >= -1 and wv.max() <= 1 - 2.0 ** -15
+    assert np.array_equal(idx, (wv * 32768).astype(np.int32))
+    assert len(np.unique(idx)) > 100                                          # a signal, not a stuck loop
+    eng.close()
+
+
+def test_config4_gauss_student_as_shipped_batch16():
+    """parallel_wavenet_gauss.json unmodified (four private deconv stacks, N(0,1) noise), 16 utterances of
+    F = 384: K2, determinism, every checked row equal to the single-utterance call, parity of one row with
+    the torch-CPU implementation."""
+    import torch
+    from oracle import wavenet_np as O
+    from oracle.torch_ref import StudentRef
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = load_json('parallel_wavenet_gauss.json')
+    hp = O.HP(cfgd)
+    assert not hp.get('use_share_deconv', False)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    assert 'iaf_4/trans_conv_2/kernel' in w and 'iaf_share/trans_conv_1/kernel' not in w
+    eng = Engine(cfgd).load_weights(w)
+    B, F, T = 16, 384, 76800
+    mel = np.random.RandomState(12345).uniform(0, 1, [B, F, 80]).astype(np.float32)
+    noise = np.random.RandomState(12346).standard_normal([B, T]).astype(np.float32)
+    a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot', 'rand_input', 'wav', 'idx'))
+    b = eng.iaf_generate(mel, noise, want=('x',))
+    assert torch.equal(a['x'], b['x'])
+    x, m, s, r = (_np(a[k]).astype(np.float64) for k in ('x', 'mean_tot', 'scale_tot', 'rand_input'))
+    assert x.shape == (B, T) and np.all(np.isfinite(x)) and np.all(s > 0)
+    assert np.array_equal(_np(a['rand_input']), noise)
+    scale = max(1.0, np.abs(x).max())
+    assert np.abs(x - (r * s + m)).max() <= 1e-6 * scale
+    wv = _np(a['wav']).astype(np.float64)
+    assert np.all(wv * 32768 == np.round(wv * 32768))
+    assert np.array_equal(_np(a['idx']), (wv * 32768).astype(np.int32))
+    for row in (0, 7, 15):
+        one = _np(eng.iaf_generate(mel[row:row + 1], noise[row:row + 1], want=('x',))['x'])
+        assert np.abs(one[0] - x[row]).max() <= 5e-6 * scale
+    # device-drawn Gaussian noise: rows differ, the call is reproducible per seed
+    c = eng.iaf_generate(mel, None, seed=11, want=('rand_input', 'x'))
+    d = eng.iaf_generate(mel, None, seed=11, want=('x',))
+    assert torch.equal(c['x'], d['x'])
+    rr = _np(c['rand_input']).astype(np.float64)
+    assert abs(rr.mean()) < 0.01 and abs(rr.var() - 1.0) < 0.01 and not np.array_equal(rr[0], rr[1])
+    eng.close()
+    ref_x = StudentRef(w, hp).feed_forward(mel[3:4], noise[3:4])['x'].astype(np.float64)
+    assert np.abs(x[3:4] - ref_x).max() <= 2e-5 * scale

@@ -257,3 +257,42 @@ def test_resize_conv_student_runs_through_the_oracle():
     mel = np.random.RandomState(0).uniform(0, 1, [1, 3, 80]).astype(np.float32)
     enc = O.deconv_stack(mel, w, hp, 'iaf_share', np.float64)
     assert enc.shape == (1, 600, 256) and np.isfinite(enc).all() and 0.05 < enc.std() < 5
+
+
+def test_scale_path_statistics_of_reference_test_scale():
+    """tests/test_scale.py:64-107 of the reference draws scale = clip(softplus(N(0,1)), e^-9, e^7) for four
+    flows and multiplies them (get_scale / reduce(np.multiply), use_log_scale=False) -- 76 800 draws.  The
+    restated `scale_log_scale` (parallel_wavenet.py:105-114) on the same kind of draws must reproduce the
+    closed-form moments of that product: E = (E s)^4 = 0.42215, std = sqrt((E s^2)^4 - (E s)^8) = 0.73625.
+    (The line the reference prints next to it, "scale.m 0.38296, scale.std 0.61160", is a log line of a
+    weight-normalised TF model, i.e. of parameters ~ N(-0.01, 0.93^2), not of N(0,1) draws: solving the two
+    moments for (mu, sigma) gives exactly that; it is therefore an order-of-magnitude check only.)"""
+    from scipy import integrate
+    pdf = lambda z: np.exp(-z * z / 2) / np.sqrt(2 * np.pi)
+    m1 = integrate.quad(lambda z: np.log1p(np.exp(z)) * pdf(z), -12, 12)[0]
+    m2 = integrate.quad(lambda z: np.log1p(np.exp(z)) ** 2 * pdf(z), -12, 12)[0]
+    assert abs(m1 - O.SOFTPLUS_N01_M1) < 1e-12 and abs(m2 - O.SOFTPLUS_N01_M2) < 1e-12
+    n = 7680 * 10
+    rs = np.random.RandomState(94107)
+    prods = []
+    for dtype in (np.float32, np.float64):
+        scales = [O.scale_log_scale(rs.standard_normal(n).astype(dtype))[0] for _ in range(4)]
+        for sc in scales:                                        # one flow
+            assert abs(sc.mean() - m1) < 5 * np.sqrt((m2 - m1 * m1) / n)
+        prods.append(np.prod(np.stack(scales).astype(np.float64), axis=0))
+    e, sd = m1 ** 4, np.sqrt(m2 ** 4 - m1 ** 8)
+    assert abs(e - 0.42215) < 1e-5 and abs(sd - 0.73625) < 1e-5
+    for pr in prods:
+        assert abs(pr.mean() - e) < 5 * sd / np.sqrt(n)
+        assert abs(pr.std() - sd) < 0.05
+        assert pr.min() > 0 and 0.2 < pr.mean() / 0.38296 < 2.0 and 0.5 < pr.std() / 0.61160 < 2.0   # same regime
+    # through the whole restated student with the probe weights: scale_tot[t] = clip(softplus(noise[t-1]))
+    cfgd = dict(load_json('parallel_wavenet.json'), num_iaf_layers=[1])
+    hp = O.HP(cfgd)
+    w = O.scale_probe_weights(hp)
+    noise = np.random.RandomState(3).standard_normal([1, 1024]).astype(np.float32)
+    mel = np.zeros([1, 6, 80], np.float32)
+    ff = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+    want = O.scale_log_scale(np.concatenate([[0.0], noise[0, :-1].astype(np.float64)]))[0]
+    assert np.abs(ff['scale_tot'][0] - want).max() <= 1e-12
+    assert np.abs(ff['mean_tot']).max() == 0.0
