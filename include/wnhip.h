@@ -208,6 +208,12 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
                    const float* forced_wav, float* out_params,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* wn_ar_generate replays the step from a hipGraph (16 steps per graph) when the caller's stream can be
+ * captured (any stream but the legacy null stream); enable = 0 makes it issue plain launches instead
+ * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  A failed capture falls back to
+ * plain launches by itself and never leaves the caller's stream in capture mode. */
+int wn_ar_set_graph(wn_handle* h, int enable);
+
 /* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher
  * handle: wav [B,T] raw audio in [-1,1] (the input encoding of wavenet.py:412-418 -- mu-law/128 when
  * use_mu_law -- is applied on the device), mel [B,F,n_mel]; out_params [B,T,out_width] are the

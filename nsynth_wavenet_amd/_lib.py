@@ -16,7 +16,7 @@ ERRNAMES = {-22: 'WN_EINVAL', -2: 'WN_ENOENT', -12: 'WN_ENOMEM', -5: 'WN_EIO', -
 # every symbol include/wnhip.h declares
 SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_iaf_length',
            'wn_ar_length', 'wn_workspace_bytes', 'wn_deconv', 'wn_iaf_generate', 'wn_clip_quant',
-           'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate',
+           'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph',
            'wn_iaf_cond_hoisted', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_last_error', 'wn_destroy']
 
 
@@ -73,6 +73,7 @@ def load():
     lib.wn_ar_reset.argtypes = [vp, vp, i32, vp]
     lib.wn_ar_step.argtypes = [vp, vp, i32, vp, vp, vp, u64, vp, vp, vp]
     lib.wn_ar_generate.argtypes = [vp, vp, i32, i32, vp, u64, vp, vp, vp, vp, vp, sz, vp]
+    lib.wn_ar_set_graph.argtypes = [vp, i32]
     lib.wn_iaf_cond_hoisted.argtypes = [vp, i32, i32]
     lib.wn_teacher_workspace_bytes.argtypes = [vp, i32, i32, i64]
     lib.wn_teacher_workspace_bytes.restype = sz

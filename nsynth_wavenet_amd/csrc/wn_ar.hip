@@ -1098,35 +1098,58 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     float* state = reinterpret_cast<float*>(ws);
     WN_HIP(h, hipMemsetAsync(state, 0, need, st));
 
-    if (!st) {
-        // the legacy null stream cannot be captured: plain launches
-        for (int t = 0; t < Tn; ++t)
+    auto plain = [&](int n) -> int {
+        for (int t = 0; t < n; ++t)
             ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
         WN_HIP(h, hipGetLastError());
         return WN_OK;
-    }
-    // Every per-step address is derived on the device from the step counter, so a
-    // captured step is static: build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay.
+    };
+    // The legacy null stream cannot be captured; WN_AR_GRAPH=0 forces plain launches (A/B runs, tests).
+    const char* eg = getenv("WN_AR_GRAPH");
+    if (!st || !h->ar_use_graph || (eg && eg[0] == '0')) return plain(Tn);
+    // Every per-step address is derived on the device from the step counter, so a captured step is static:
+    // build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay.  A failed capture is always closed (the
+    // caller's stream must not be left in capture mode), its partial graph destroyed, and the call falls
+    // back to plain launches.
     wn_ar_release(h);
     ArGraphCache* gc = new ArGraphCache();
     h->ar_graph_cache = gc;
     gc->stream = st;
-    const int multi = Tn / AR_GRAPH_STEPS, rest = Tn % AR_GRAPH_STEPS;
-    if (multi) {
-        WN_HIP(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < AR_GRAPH_STEPS; ++i)
+    auto capture = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        for (int i = 0; i < nsteps; ++i)
             ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
-        WN_HIP(h, hipStreamEndCapture(st, &gc->g_multi));
-        WN_HIP(h, hipGraphInstantiate(&gc->exec_multi, gc->g_multi, nullptr, nullptr, 0));
-    }
-    if (rest) {
-        WN_HIP(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
-        WN_HIP(h, hipStreamEndCapture(st, &gc->g_one));
-        WN_HIP(h, hipGraphInstantiate(&gc->exec_one, gc->g_one, nullptr, nullptr, 0));
+        const hipError_t e1 = hipGetLastError();
+        const hipError_t e2 = hipStreamEndCapture(st, g);            // always: leaves capture mode
+        if (e1 != hipSuccess || e2 != hipSuccess || !*g ||
+            hipGraphInstantiate(ex, *g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (*g) (void)hipGraphDestroy(*g);
+            *g = nullptr;
+            *ex = nullptr;
+            return false;
+        }
+        return true;
+    };
+    const int multi = Tn / AR_GRAPH_STEPS, rest = Tn % AR_GRAPH_STEPS;
+    bool ok = true;
+    if (multi) ok = capture(AR_GRAPH_STEPS, &gc->g_multi, &gc->exec_multi);
+    if (ok && rest) ok = capture(1, &gc->g_one, &gc->exec_one);
+    if (!ok) {
+        wn_ar_release(h);
+        return plain(Tn);
     }
     for (int i = 0; i < multi; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_multi, st));
     for (int i = 0; i < rest; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_one, st));
+    return WN_OK;
+}
+
+extern "C" int wn_ar_set_graph(wn_handle* h, int enable) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_ar_set_graph: null handle");
+    h->ar_use_graph = enable != 0;
     return WN_OK;
 }
 

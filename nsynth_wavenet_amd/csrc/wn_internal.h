@@ -117,6 +117,7 @@ struct wn_handle {
     mutable std::string err;
     // cached hipGraph for the AR step (wn_ar.hip)
     void* ar_graph_cache = nullptr;
+    bool ar_use_graph = true;                 // wn_ar_set_graph
     // bench.py measurement aid (wn_profile_begin/end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // begin/end pairs

@@ -32,10 +32,8 @@ def main(argv=None):
     if args.format == 'npz':
         path = wts.save_checkpoint(out, w, hp)
     else:
-        raw = set()
-        if getattr(hp, 'use_teacher_deconv', False):
-            raw = {k for k in w if k.startswith('iaf_share/trans_conv')}
-        path = tf_bundle.write_bundle(out, {k if k in raw else k + wts.EMA: v for k, v in w.items()})
+        keys = wts.checkpoint_keys(w, hp)                 # one rule for both writers (weights.raw_name_variables)
+        path = tf_bundle.write_bundle(out, {keys[k]: v for k, v in w.items()})
         with open(os.path.join(args.out_dir, 'checkpoint'), 'wt') as f:
             f.write('model_checkpoint_path: "{}"\n'.format(base))
     import glob

@@ -118,14 +118,27 @@ def synthetic_weights(hp, kind=None, seed=1234, init='tf', n_mel=80):
     return w
 
 
+def raw_name_variables(names, hp):
+    """Variables a generation checkpoint stores under their RAW name instead of '<name>/ExponentialMovingAverage':
+    the teacher-owned upsampler of a student built with use_teacher_deconv (the reference's restore map looks
+    those up by raw name, parallelgen.py:31-39) -- transposed-conv and resize-conv flavours alike."""
+    if hp is None or not getattr(hp, 'use_teacher_deconv', False):
+        return set()
+    return {k for k in names if k.startswith(('iaf_share/trans_conv', 'iaf_share/resize_conv'))}
+
+
+def checkpoint_keys(weights, hp=None, ema=True):
+    """name -> checkpoint key, the convention the reference's Saver maps use (fastgen.py:12-14)."""
+    raw = raw_name_variables(weights, hp)
+    return {k: (k if (not ema or k in raw) else k + EMA) for k in weights}
+
+
 def save_checkpoint(path, weights, hp=None, ema=True):
     """Write an .npz with the key convention the reference's Saver maps use."""
-    raw = set()
-    if hp is not None and getattr(hp, 'use_teacher_deconv', False):
-        raw = {k for k in weights if k.startswith(('iaf_share/trans_conv', 'iaf_share/resize_conv'))}   # parallelgen.py:31-39
+    keys = checkpoint_keys(weights, hp, ema)
     out = {}
     for k, v in weights.items():
-        out[k if (not ema or k in raw) else k + EMA] = np.asarray(v, np.float32)
+        out[keys[k]] = np.asarray(v, np.float32)
     np.savez(path, **out)
     return path if path.endswith('.npz') else path + '.npz'
 

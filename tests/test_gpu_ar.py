@@ -211,3 +211,61 @@ def test_teacher_resize_conv_encoding():
     res = eng.ar_generate(enc, forced_wav=forced, want_out=True)
     assert np.abs(_np(res['out_params']) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
     eng.close()
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_graph_replay_matches_plain_launches_and_inputs_are_checked(B):
+    """wn_ar_generate replays the step from hipGraphs (16 steps per graph + single-step graphs for the rest) when
+    the stream can be captured -- Engine.ar_generate runs it on a side stream for that reason -- and issues plain
+    launches otherwise (use_graph=False -> wn_ar_set_graph(0)).  Same kernels, same order: bitwise equal results,
+    teacher-forced and free-running, for the GEMV step (B < 4) and the batched MFMA step.  Mis-shaped inputs
+    raise before anything reaches the device."""
+    import torch
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, 'ar_mol.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    rs = np.random.RandomState(B)
+    Tn = 37                                                   # 2 x 16-step graphs + 5 single-step replays
+    enc = (rs.standard_normal([B, Tn, hp.deconv_width]) * 0.5).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    rnd = rs.uniform(1e-5, 1 - 1e-5, [Tn, B, eng.ar_n_rand()]).astype(np.float32)
+    for kw in (dict(forced_wav=forced), dict()):
+        a = eng.ar_generate(enc, rnd, want_out=True, use_graph=True, **kw)
+        b = eng.ar_generate(enc, rnd, want_out=True, use_graph=False, **kw)
+        c = eng.ar_generate(enc, rnd, want_out=True, use_graph=True, **kw)      # a second capture on the same handle
+        for k in ('idx', 'wav', 'out_params'):
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    # the caller's stream is usable afterwards and sees the results (the side stream was joined)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = eng.ar_generate(enc, rnd, want_out=True)
+        assert torch.equal(d['idx'], a['idx'])
+    with pytest.raises(ValueError):
+        eng.ar_generate(enc, np.transpose(rnd, (1, 0, 2)))                       # [B,Tn,n] instead of [Tn,B,n]
+    with pytest.raises(ValueError):
+        eng.ar_generate(enc, rnd, forced_wav=forced[:, :-1])
+    with pytest.raises(ValueError):
+        eng.ar_generate(enc[:, :, :-1], rnd)
+    st = eng.ar_new_state(B)
+    with pytest.raises(ValueError):
+        eng.ar_step(torch.empty(4096, dtype=torch.uint8, device='cuda'), np.zeros([B], np.float32), enc[:, 0], rnd[0])
+    with pytest.raises(ValueError):
+        eng.ar_step(st, np.zeros([B], np.float32), enc[:, 0, :-1], rnd[0])
+    with pytest.raises(ValueError):
+        eng.ar_step(st, np.zeros([B], np.float32), enc[:, 0], rnd[0][:, :-1])
+    eng.close()
+
+
+def test_teacher_configs_outside_the_kernel_limits_are_refused():
+    """The AR step kernels hold one weight row in a fixed register tile: 3*width + deconv_width <= 2048,
+    gate_width/2 <= 1024, 1 <= mol_mix <= 64 -- anything else must fail at wn_create, not truncate a dot product."""
+    from nsynth_wavenet_amd.engine import Engine
+    base = load_json('wavenet_mol.json')
+    for bad in (dict(width=768, skip_width=256), dict(mol_mix=65), dict(mol_mix=0)):
+        with pytest.raises(ValueError):
+            Engine(dict(base, **bad))
+    Engine(dict(base, mol_mix=64)).close()

@@ -378,19 +378,35 @@ def test_resize_conv_upsampler(precision):
         eng.close()
 
 
-def test_device_mel_featuriser_matches_host_featuriser():
-    """auxilaries/mel_extractor.py: the GPU featuriser (rocFFT + matmul) against the numpy restatement
-    on noise, a tone and silence, including the reference fixture length (154 480 samples -> 773 frames)."""
+def test_device_mel_featuriser_against_analysis():
+    """auxilaries/mel_extractor.py on the GPU (rocFFT + one matmul) against CLOSED FORMS -- two stationary tones
+    (the Hann window's DTFT at the bin offsets) and a unit impulse (the window sample, flat over frequency) --
+    and against the float64 oracle featuriser (oracle/mel_np.py, explicit DFT) on noise, incl. the reference
+    fixture length (154 480 samples -> 773 frames).  The host featuriser has the same test in tests/test_mel.py."""
     import torch
     from nsynth_wavenet_amd.auxilaries import mel_extractor as M
+    from oracle import mel_np as OM
+    n = 8000
+    t = np.arange(n) / 16000.0
+    imp = np.zeros(n)
+    imp[4000] = 1.0
     rs = np.random.RandomState(0)
-    t = np.arange(154480) / 16000.0
-    wavs = np.stack([rs.uniform(-0.5, 0.5, 154480), 0.3 * np.sin(2 * np.pi * 440.0 * t), np.zeros(154480)]).astype(np.float32)
+    wavs = np.stack([0.5 * np.sin(2 * np.pi * 1000.0 * t + 0.3), 0.25 * np.sin(2 * np.pi * 3437.5 * t + 1.1), imp,
+                     rs.uniform(-0.5, 0.5, n), np.zeros(n)]).astype(np.float32)
     dev = M.batch_melspectrogram_device(wavs)
-    assert dev.is_cuda and tuple(dev.shape) == (3, 773, 80) and dev.dtype == torch.float32
-    host = M.batch_melspectrogram(wavs)
-    assert np.abs(_np(dev) - host).max() <= 2e-4
-    assert float(dev[2].max()) == float(host[2].max())          # silence sits on the floor (40/140)
+    assert dev.is_cuda and tuple(dev.shape) == (5, 41, 80) and dev.dtype == torch.float32
+    got = _np(dev).astype(np.float64)
+    for row, (f, a) in enumerate(((1000.0, 0.5), (3437.5, 0.25))):
+        want = OM.analytic_tone_mel(f, a)
+        near = want >= want.max() - 60.0 / 140.0
+        assert np.abs(got[row, 15:26][:, near] - want[None, near]).max() < 2e-4
+    assert np.abs(got[2] - OM.analytic_impulse_mel(4000, n)).max() < 5e-5
+    assert np.abs(got[3] - OM.melspectrogram(wavs[3])).max() < 2e-4
+    assert np.all(got[4] == np.float32(40.0 / 140.0))               # silence sits on the floor (1e-5 -> -100 dB)
+    long = M.batch_melspectrogram_device(rs.uniform(-0.5, 0.5, [2, 154480]).astype(np.float32))
+    assert tuple(long.shape) == (2, 773, 80)
+    host = M.batch_melspectrogram(wavs)                              # the product's two implementations agree as well
+    assert np.abs(got - host).max() <= 2e-4
 
 
 def test_full_size_batch8_hoisted_conditioning():

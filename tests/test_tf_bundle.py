@@ -104,3 +104,155 @@ def test_weights_load_from_tf_bundle_and_cli_resolution(tmp_path):
         assert all(np.array_equal(got[k], w[k]) for k in w)
     r = tb.BundleReader(str(tmp_path / 'eval_tf' / 'model.ckpt-3'))
     assert all(k.endswith(wts.EMA) for k in r.entries) and len(r.entries) == len(w)
+
+
+# ---- a second, writer-independent fixture: every byte below is produced by the helpers of THIS file from the
+# ---- format description (LevelDB table format + tensor_bundle.proto), never by tf_bundle.write_bundle
+def _vi(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _entry_proto(dtype, shape, shard, offset, size, crc, sliced=False):
+    dims = b''.join(b'\x12' + _vi(len(d)) + d for d in (b'\x08' + _vi(n) for n in shape))
+    out = b'\x08' + _vi(dtype) + b'\x12' + _vi(len(dims)) + dims
+    if shard:
+        out += b'\x18' + _vi(shard)
+    if offset:
+        out += b'\x20' + _vi(offset)
+    out += b'\x28' + _vi(size) + b'\x35' + struct.pack('<I', crc)
+    if sliced:                       # repeated TensorSliceProto slices = 7: one slice with one extent {start 0, length 2}
+        ext = b'\x08\x00\x10\x02'
+        sl = b'\x0a' + _vi(len(ext)) + ext
+        out += b'\x3a' + _vi(len(sl)) + sl
+    return out
+
+
+def _table_block(items, restart_every):
+    """(key, value) list -> block bytes with PREFIX-COMPRESSED keys and a restart array."""
+    out, restarts, last = bytearray(), [], b''
+    for i, (k, v) in enumerate(items):
+        shared = 0
+        if i % restart_every == 0:
+            restarts.append(len(out))
+        else:
+            while shared < min(len(k), len(last)) and k[shared] == last[shared]:
+                shared += 1
+        out += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
+        last = k
+    for r in restarts:
+        out += struct.pack('<I', r)
+    return bytes(out) + struct.pack('<I', len(restarts))
+
+
+def _frame(block):
+    return block + b'\x00' + struct.pack('<I', tb.mask_crc(tb.crc32c(block + b'\x00')))
+
+
+def test_reader_on_hand_assembled_multi_block_two_shard_bundle(tmp_path):
+    """Two data shards, three data blocks, keys sharing long prefixes (prefix compression with restart interval 2,
+    so both restart and non-restart entries occur), an int64 scalar, an empty tensor, a tensor whose stored
+    shape differs from the variable's (Saver(reshape=True), parallelgen.py:40) and a partitioned entry
+    (slices present), which must be refused by name."""
+    prefix = str(tmp_path / 'model.ckpt-42')
+    rs = np.random.RandomState(1)
+    t = {
+        'iaf_1/dilated_conv_1/W/ExponentialMovingAverage': rs.standard_normal([1, 3, 4, 8]).astype('<f4'),
+        'iaf_1/dilated_conv_1/biases/ExponentialMovingAverage': rs.standard_normal([8]).astype('<f4'),
+        'iaf_1/dilated_conv_2/W/ExponentialMovingAverage': rs.standard_normal([1, 3, 4, 8]).astype('<f4'),
+        'iaf_1/out2_scale/W/ExponentialMovingAverage': rs.standard_normal([4, 1]).astype('<f4'),     # stored [4,1], variable [1,1,4,1]
+        'global_step': np.array(42, '<i8'),
+        'zero_len': np.zeros([0, 3], '<f4'),
+    }
+    order = sorted(t)
+    shard_of = {k: (1 if 'dilated_conv_2' in k or k == 'zero_len' else 0) for k in order}
+    blobs, offs = {0: bytearray(), 1: bytearray()}, {}
+    for k in order:
+        offs[k] = len(blobs[shard_of[k]])
+        blobs[shard_of[k]] += t[k].tobytes()
+    for sid in (0, 1):
+        open('{}.data-{:05d}-of-00002'.format(prefix, sid), 'wb').write(bytes(blobs[sid]))
+    dt = {np.dtype('<f4'): 1, np.dtype('<i8'): 9}
+    items = [(b'', b'\x08\x02' + b'\x1a\x02\x08\x01')]                      # header: num_shards 2, version.producer 1
+    for k in order:
+        raw = t[k].tobytes()
+        items.append((k.encode(), _entry_proto(dt[t[k].dtype], t[k].shape, shard_of[k], offs[k], len(raw),
+                                               tb.mask_crc(tb.crc32c(raw)))))
+    items.append((b'part/W', _entry_proto(1, [4, 2], 0, 0, 0, 0, sliced=True)))
+    items.sort(key=lambda kv: kv[0])
+    groups = [items[:3], items[3:5], items[5:]]                             # three data blocks
+    out, index_items = bytearray(), []
+    for g in groups:
+        blk = _table_block(g, restart_every=2)
+        index_items.append((g[-1][0], _vi(len(out)) + _vi(len(blk))))
+        out += _frame(blk)
+    meta = _table_block([], 1) if False else struct.pack('<II', 0, 1)
+    meta_off = len(out)
+    out += _frame(meta)
+    index = _table_block(index_items, restart_every=1)
+    index_off = len(out)
+    out += _frame(index)
+    footer = _vi(meta_off) + _vi(len(meta)) + _vi(index_off) + _vi(len(index))
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
+    open(prefix + '.index', 'wb').write(bytes(out) + footer)
+    # the prefix compression really is exercised: some entry shares >= 20 key bytes with its predecessor
+    assert any(a[0][:20] == b[0][:20] and len(a[0]) > 20 for a, b in zip(items, items[1:]))
+
+    r = tb.BundleReader(prefix)
+    assert r.num_shards == 2 and sorted(r.entries) == sorted(order + ['part/W'])
+    for k in order:
+        got = r.get_tensor(k, verify=True)
+        assert got.dtype == t[k].dtype.newbyteorder('=') and got.shape == t[k].shape and np.array_equal(got, t[k])
+    assert r.get_variable_to_shape_map()['global_step'] == [] and int(r.get_tensor('global_step')) == 42
+    with pytest.raises(ValueError, match='part/W'):
+        r.get_tensor('part/W')
+    # reshape=True semantics of the loader: [4,1] in the file feeds a [1,1,4,1] variable; a wrong element count does not
+    from nsynth_wavenet_amd.weights import _BundleView
+    view = _BundleView(prefix)
+    arr = np.asarray(view['iaf_1/out2_scale/W/ExponentialMovingAverage'])
+    assert arr.reshape([1, 1, 4, 1]).shape == (1, 1, 4, 1)
+    # `checkpoint` state file (run_all_eval.py:44-49 writes exactly these two lines): relative and absolute paths,
+    # and a stale entry falls back to the highest-numbered bundle
+    d = str(tmp_path)
+    open(os.path.join(d, 'checkpoint'), 'wt').write('model_checkpoint_path: "model.ckpt-42"\nall_model_checkpoint_paths: "model.ckpt-42"\n')
+    assert wts.latest_checkpoint(d) == prefix
+    open(os.path.join(d, 'checkpoint'), 'wt').write('model_checkpoint_path: "{}"\n'.format(prefix))
+    assert wts.latest_checkpoint(d) == prefix
+    open(os.path.join(d, 'checkpoint'), 'wt').write('model_checkpoint_path: "model.ckpt-99"\n')
+    assert wts.latest_checkpoint(d) == prefix
+
+
+def test_teacher_owned_resize_conv_upsampler_keeps_raw_names_in_both_writers(tmp_path):
+    """use_teacher_deconv + use_resize_conv: the reference's restore map (parallelgen.py:31-39) looks the
+    teacher-owned upsampler up by RAW variable name; both checkpoint writers (npz and TF bundle) must store it
+    that way (one rule: weights.raw_name_variables) and both must load back."""
+    import json
+    from nsynth_wavenet_amd import cli
+    from nsynth_wavenet_amd.tools import make_eval_model
+    d = dict(load_json('parallel_wavenet.json'), num_iaf_layers=[1, 1], use_teacher_deconv=True, use_resize_conv=True,
+             deconv_config=[[7, 2], [12, 4]], num_iters=1)
+    d.pop('use_share_deconv', None)
+    hp = cfg.load_hparams(d)
+    w = wts.synthetic_weights(hp, seed=6)
+    raw = wts.raw_name_variables(w, hp)
+    assert raw and all(k.startswith('iaf_share/resize_conv') for k in raw)
+    run = tmp_path / 'run'
+    run.mkdir()
+    wts.save_checkpoint(str(run / 'model.ckpt-5'), w, hp)
+    (run / 'cfg.json').write_text(json.dumps(d))
+    for fmt in ('tf', 'npz'):
+        out = tmp_path / ('eval_' + fmt)
+        make_eval_model.main(['--ckpt_dir', str(run), '--out_dir', str(out), '--format', fmt])
+        hp2, ck = cli.resolve_model(str(out))
+        if fmt == 'tf':
+            keys = set(tb.BundleReader(ck).entries)
+        else:
+            keys = set(np.load(ck if ck.endswith('.npz') else ck + '.npz').files)
+        assert keys == {k if k in raw else k + wts.EMA for k in w}
+        back = wts.load_checkpoint(ck, hp2)
+        assert all(np.array_equal(back[k], w[k]) for k in w)
