@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 
+#include <cstdlib>
 #include "wn_internal.h"
 
 static std::string g_create_err;
@@ -99,7 +100,7 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
     if (c.precision != WN_PREC_F16X3 && c.precision != WN_PREC_F32)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
-    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_PIPE)
+    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_RESIDENT)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)
@@ -157,7 +158,16 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         return wn_fail(nullptr, WN_EIO, "wn_create: hipGetDevice failed");
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
+        h->num_cu = prop.multiProcessorCount;
+        h->hoist_limit_bytes = (double)prop.totalGlobalMem / 3.0;   // 96 GB on a 288 GB MI355X
+    }
+    if (const char* e = getenv("WN_COND")) {                         // read ONCE: sizing and generate calls must agree
+        if (!strcmp(e, "fused")) h->cond_env_mode = WN_COND_FUSED;
+        else if (!strcmp(e, "hoisted")) h->cond_env_mode = WN_COND_HOISTED;
+        else if (!strcmp(e, "pipe")) h->cond_env_mode = WN_COND_PIPE;
+        else if (!strcmp(e, "resident")) h->cond_env_mode = WN_COND_RESIDENT;
+    }
     h->frame_shift = 1;
     for (int j = 0; j < cfg->n_deconv; ++j) h->frame_shift *= cfg->deconv_stride[j];
 

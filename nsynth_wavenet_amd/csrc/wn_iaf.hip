@@ -437,6 +437,29 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F) {
     L.form = wn_iaf_form(h, B, L.T);
     L.pipe_chunk = L.pipe_layers = L.pipe_stacks = 0;
     L.cnt = L.enc_stack_floats = 0;
+    if (L.form == WN_COND_RESIDENT && L.T > 0) {
+        // segment-resident form: one image of enc per deconv stack, max-layers-per-flow + 1 activation buffers of
+        // ONE utterance (reused across flows and utterances: kernel boundaries separate the uses), progress words
+        int mx = 0;
+        for (const IafFlowPack& fp : h->flows) mx = std::max(mx, (int)fp.layers.size());
+        L.pipe_layers = mx + 1;
+        L.pipe_stacks = h->cfg.share_deconv ? 1 : h->cfg.n_flows;
+        L.enc_stack_floats = align_up((size_t)B * IAF_CD * L.TE + 64, 64);
+        L.enc = carve(L.enc_stack_floats * L.pipe_stacks);
+        L.lA = carve((size_t)L.pipe_layers * IAF_W * L.RS);
+        L.lB = L.lA;
+        L.x = carve((size_t)B * L.XR);
+        L.x0 = carve((size_t)B * L.T);
+        L.M = carve((size_t)B * L.T);
+        L.S = carve((size_t)B * L.T);
+        L.cnt = carve((size_t)h->num_cu * 4 + 64);
+        L.c_bstride = 0;
+        L.C = o;
+        L.scratch = o;
+        o += wn_deconv_scratch_bytes(h, B, F);
+        L.total = o;
+        return L;
+    }
     if (L.form == WN_COND_PIPE && L.T > 0) {
         for (const IafFlowPack& fp : h->flows) L.pipe_layers += (int)fp.layers.size();
         L.pipe_stacks = h->cfg.share_deconv ? 1 : h->cfg.n_flows;
@@ -585,6 +608,85 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
+// The segment-resident form of a generate call (wn_iaf_s.hip): per utterance and flow, the start conv, then all
+// residual layers in ONE launch per pass of <= 256 x 192 columns, then the flow head.
+static int iaf_generate_resident(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
+                                 uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
+                                 float* scale_tot, float* rand_out, char* base, hipStream_t st) {
+    const wn_config& c = h->cfg;
+    float* enc = reinterpret_cast<float*>(base + L.enc);
+    float* lbuf = reinterpret_cast<float*>(base + L.lA);
+    float* x = reinterpret_cast<float*>(base + L.x);
+    float* x0g = reinterpret_cast<float*>(base + L.x0);
+    float* Mt = reinterpret_cast<float*>(base + L.M);
+    float* St = reinterpret_cast<float*>(base + L.S);
+    unsigned* flags = reinterpret_cast<unsigned*>(base + L.cnt);
+    void* scratch = base + L.scratch;
+    const size_t buf_floats = (size_t)IAF_W * L.RS;
+    WN_HIP(h, hipMemsetAsync(x, 0, (size_t)B * L.XR * sizeof(float), st));
+    WN_HIP(h, hipMemsetAsync(flags, 0, ((size_t)h->num_cu * 4 + 1) * sizeof(unsigned), st));
+    const float* x0 = noise;
+    {
+        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+        if (noise) {
+            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
+        } else {
+            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
+                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
+            x0 = x0g;
+        }
+    }
+    wn_iaf_p_zero_pads(reinterpret_cast<unsigned*>(lbuf), L.RS, L.pipe_layers * 16, st);
+    for (int s = 0; s < L.pipe_stacks; ++s) {
+        const int si = c.share_deconv ? 0 : h->flows[s].deconv_stack;
+        int rc = wn_run_deconv(h, si, mel, B, F, enc + (size_t)s * L.enc_stack_floats, L.TE, scratch, st, true);
+        if (rc) return rc;
+    }
+    const int max_blk = wn_iaf_s_max_cols(h) / 16, nblk_tot = (int)(L.T / 16);
+    unsigned epoch = 0;
+    if (h->prof_on) {
+        hipEvent_t ev;
+        WN_HIP(h, hipEventCreate(&ev));
+        h->prof_events.push_back(ev);
+        WN_HIP(h, hipEventRecord(ev, st));
+    }
+    for (int b = 0; b < B; ++b) {
+        float* xb = x + (size_t)b * L.XR;
+        for (int k = 0; k < c.n_flows; ++k) {
+            const IafFlowPack& fp = h->flows[k];
+            const float* enc_b = enc + (size_t)(c.share_deconv ? 0 : k) * L.enc_stack_floats + (size_t)b * IAF_CD * L.TE;
+            wn_iaf_h_start(xb, h->d_blob + fp.start_off, lbuf, L.T, L.XR, L.RS, 1, st);
+            // full passes first: 12 blocks per CU keep the four waves of every CU equally loaded
+            for (int b0 = 0; b0 < nblk_tot; b0 += max_blk) {
+                epoch += 256;
+                int rc = wn_iaf_s_flow(h, fp, reinterpret_cast<const unsigned*>(enc_b), reinterpret_cast<unsigned*>(lbuf),
+                                       L.RS, L.TE, L.c0, 16 * b0, std::min(max_blk, nblk_tot - b0), flags, epoch, st);
+                if (rc) return rc;
+                if (h->prof_on) ++h->prof_launches;
+            }
+            wn_iaf_h_head(lbuf + fp.layers.size() * buf_floats, enc_b, h->d_blob + fp.head_off_h, xb, Mt + (size_t)b * L.T,
+                          St + (size_t)b * L.T, L.RS, L.TE, L.c0, L.XR, L.T, k == 0 ? 1 : 0, 1, h->num_cu, st);
+        }
+    }
+    if (h->prof_on) {
+        hipEvent_t ev;
+        WN_HIP(h, hipEventCreate(&ev));
+        h->prof_events.push_back(ev);
+        WN_HIP(h, hipEventRecord(ev, st));
+    }
+    {
+        const int64_t nn = (int64_t)B * L.T;
+        const int Q = c.use_mu_law ? 256 : 65536;
+        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
+                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
+        wn_iaf_p_poison(flags + (size_t)h->num_cu * 4, wav, nn, st);
+        if (rand_out && rand_out != x0)
+            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
 // The flow-pipeline form of a generate call (wn_iaf_p.hip): upsampler(s), then every layer and head of
 // every flow in ONE persistent launch per batch chunk, then the final affine + quantiser.
 static int iaf_generate_pipe(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
@@ -704,6 +806,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         if (rc) return rc;
         rc = wn_iaf_p_set_attrs(h);
         if (rc) return rc;
+        rc = wn_iaf_s_set_attrs(h);
+        if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_LAYER_FLOATS * sizeof(float)));
@@ -713,6 +817,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         h->iaf_attrs_set = true;
     }
 
+    if (L.form == WN_COND_RESIDENT)
+        return iaf_generate_resident(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
     if (L.form == WN_COND_PIPE)
         return iaf_generate_pipe(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
 
@@ -876,32 +982,28 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 int wn_iaf_form(const wn_handle* h, int B, int64_t T) {
     if (h->cfg.precision != WN_PREC_F16X3) return WN_COND_FUSED;
     int mode = h->cfg.cond_mode;
-    if (mode == WN_COND_AUTO) {
-        const char* e = getenv("WN_COND");
-        if (e && !strcmp(e, "fused")) mode = WN_COND_FUSED;
-        else if (e && !strcmp(e, "hoisted")) mode = WN_COND_HOISTED;
-        else if (e && !strcmp(e, "pipe")) mode = WN_COND_PIPE;
-    }
+    if (mode == WN_COND_AUTO) mode = h->cond_env_mode;           // WN_COND, resolved once in wn_create
     if (mode == WN_COND_PIPE) return wn_iaf_p_supported(h) ? WN_COND_PIPE : WN_COND_FUSED;
+    if (mode == WN_COND_RESIDENT) {
+        for (const IafFlowPack& fp : h->flows)
+            if (fp.layers.empty() || (int)fp.layers.size() > wn_iaf_s_max_layers()) return WN_COND_FUSED;
+        return WN_COND_RESIDENT;
+    }
     if (mode == WN_COND_FUSED) return WN_COND_FUSED;
     if (mode == WN_COND_HOISTED) return WN_COND_HOISTED;
     return wn_iaf_hoisted(h, B, T) ? WN_COND_HOISTED : WN_COND_FUSED;
 }
 
+// Default placement (cond_mode 0, no WN_COND): hoisted while the projected term (256 B per sample and row
+// block) stays below a third of the device memory, else the fused form, which needs no such workspace.
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
-    if (h->cfg.precision != WN_PREC_F16X3 || h->cfg.cond_mode == WN_COND_FUSED) return false;
-    if (h->cfg.cond_mode == WN_COND_HOISTED) return true;
-    if (h->cfg.cond_mode == WN_COND_PIPE) return false;
-    const char* e = getenv("WN_COND");
-    if (e && (!strcmp(e, "fused") || !strcmp(e, "pipe"))) return false;
-    // the projected term costs 256 B per sample and row block; past a third of the 288 GB of HBM the call
-    // falls back to the fused form, which needs no such workspace
+    if (h->cfg.precision != WN_PREC_F16X3) return false;
     int rows = h->cond_rows;
     if (!h->cfg.share_deconv) {
         rows = 0;
         for (const IafFlowPack& fp : h->flows) rows = std::max(rows, (int)fp.layers.size() + 1);
     }
-    return (double)B * (double)T * 256.0 * rows <= 96e9;
+    return (double)B * (double)T * 256.0 * rows <= h->hoist_limit_bytes;
 }
 
 extern "C" int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F) {

@@ -114,6 +114,9 @@ struct wn_handle {
     int pipe_stages = 0;
     int frame_shift = 1;
     int num_cu = 256;
+    // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
+    int cond_env_mode = 0;                    // WN_COND_AUTO or the form named by the environment
+    double hoist_limit_bytes = 96e9;          // a third of the device memory
     mutable std::string err;
     // cached hipGraph for the AR step (wn_ar.hip)
     void* ar_graph_cache = nullptr;
@@ -153,6 +156,7 @@ constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
 constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB Infinity Cache, else fused
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
+constexpr int WN_COND_RESIDENT = 4; // every layer of a flow in ONE launch, activations resident per CU (wn_iaf_s.hip)
 constexpr int WN_COND_PIPE = 3;    // fused form, all layers and heads as ONE persistent pipeline launch (wn_iaf_p.hip)
 
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
@@ -221,7 +225,13 @@ int wn_iaf_p_chunk(const wn_handle* h, int B, int64_t T);
 int wn_iaf_p_run(wn_handle* h, const WnPipeBufs& P, int B0, int Bc, hipStream_t st);
 void wn_iaf_p_zero_pads(unsigned* lbuf, int64_t RS, int rows, hipStream_t st);
 void wn_iaf_p_poison(const unsigned* err, float* wav, int64_t n, hipStream_t st);
-int wn_iaf_form(const wn_handle* h, int B, int64_t T);   // WN_COND_FUSED / _HOISTED / _PIPE for this call
+int wn_iaf_form(const wn_handle* h, int B, int64_t T);
+// ---- segment-resident flow kernel (wn_iaf_s.hip) ----
+int wn_iaf_s_set_attrs(wn_handle* h);
+int wn_iaf_s_max_cols(const wn_handle* h);
+int wn_iaf_s_max_layers();
+int wn_iaf_s_flow(wn_handle* h, const IafFlowPack& fp, const unsigned* enc_utt, unsigned* lbuf, int64_t RS, int64_t TE,
+                  int c0, int col0, int nblk, unsigned* flags, unsigned epoch, hipStream_t st);   // WN_COND_FUSED / _HOISTED / _PIPE for this call
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);

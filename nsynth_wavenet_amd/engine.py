@@ -92,7 +92,12 @@ class Engine(object):
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            try:
+                self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            except torch.cuda.OutOfMemoryError as e:
+                raise MemoryError('workspace of {:.1f} GB does not fit on {} ({}); for the IAF path '
+                                  "precision='f16x3-fused' needs no conditioning workspace, or split the batch"
+                                  .format(nbytes / 1e9, self.device, str(e).splitlines()[0]))
         return self._ws
 
     def _dev(self, x, dtype=torch.float32):
