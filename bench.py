@@ -268,7 +268,7 @@ def main():
                     help='skip the second roofline block (8 utterances per GPU) and the PCIe-inclusive timing')
     ap.add_argument('--layer-events-every', type=int, default=4,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
-    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f32'],
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f16x3-hoisted-resident', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -100,7 +100,7 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
     if (c.precision != WN_PREC_F16X3 && c.precision != WN_PREC_F32)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
-    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_RESIDENT)
+    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_RESHOIST)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)
@@ -167,6 +167,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         else if (!strcmp(e, "hoisted")) h->cond_env_mode = WN_COND_HOISTED;
         else if (!strcmp(e, "pipe")) h->cond_env_mode = WN_COND_PIPE;
         else if (!strcmp(e, "resident")) h->cond_env_mode = WN_COND_RESIDENT;
+        else if (!strcmp(e, "hoisted-resident")) h->cond_env_mode = WN_COND_RESHOIST;
     }
     h->frame_shift = 1;
     for (int j = 0; j < cfg->n_deconv; ++j) h->frame_shift *= cfg->deconv_stride[j];

@@ -437,6 +437,27 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F) {
     L.form = wn_iaf_form(h, B, L.T);
     L.pipe_chunk = L.pipe_layers = L.pipe_stacks = 0;
     L.cnt = L.enc_stack_floats = 0;
+    if (L.form == WN_COND_RESHOIST && L.T > 0) {
+        // hoisted GEMM + resident layers: enc, the projected term C of every row block (all utterances), max-layers + 1
+        // activation buffers of ONE utterance, progress words
+        int mx = 0;
+        for (const IafFlowPack& fp : h->flows) mx = std::max(mx, (int)fp.layers.size());
+        L.pipe_layers = mx + 1;
+        L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
+        L.lA = carve((size_t)L.pipe_layers * IAF_W * L.RS);
+        L.lB = L.lA;
+        L.x = carve((size_t)B * L.XR);
+        L.x0 = carve((size_t)B * L.T);
+        L.M = carve((size_t)B * L.T);
+        L.S = carve((size_t)B * L.T);
+        L.cnt = carve((size_t)h->num_cu * 16 + 64);
+        L.c_bstride = (int64_t)wn_iaf_c_floats(h->cfg.share_deconv ? h->cond_rows : mx + 1, L.T);
+        L.C = carve((size_t)B * L.c_bstride);
+        L.scratch = o;
+        o += wn_deconv_scratch_bytes(h, B, F);
+        L.total = o;
+        return L;
+    }
     if (L.form == WN_COND_RESIDENT && L.T > 0) {
         // segment-resident form: one image of enc per deconv stack, max-layers-per-flow + 1 activation buffers of
         // ONE utterance (reused across flows and utterances: kernel boundaries separate the uses), progress words
@@ -605,6 +626,98 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
         }
         h->flows.push_back(fp);
     }
+    return WN_OK;
+}
+
+// Hoisted conditioning GEMM + resident layers (wn_iaf_r.hip): per deconv stack the upsampler and ONE GEMM for all
+// utterances; then per utterance and flow the start conv, all residual layers in ONE launch per pass of
+// <= 256 x 128 columns, and the flow head.
+static int iaf_generate_reshoist(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
+                                 uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
+                                 float* scale_tot, float* rand_out, char* base, hipStream_t st) {
+    const wn_config& c = h->cfg;
+    float* enc = reinterpret_cast<float*>(base + L.enc);
+    float* lbuf = reinterpret_cast<float*>(base + L.lA);
+    float* x = reinterpret_cast<float*>(base + L.x);
+    float* x0g = reinterpret_cast<float*>(base + L.x0);
+    float* Mt = reinterpret_cast<float*>(base + L.M);
+    float* St = reinterpret_cast<float*>(base + L.S);
+    float* Cc = reinterpret_cast<float*>(base + L.C);
+    unsigned* flags = reinterpret_cast<unsigned*>(base + L.cnt);
+    void* scratch = base + L.scratch;
+    const size_t buf_floats = (size_t)IAF_W * L.RS;
+    const size_t rb_floats = (size_t)(L.T / 16) * 1024;
+    const unsigned* cond_tab = reinterpret_cast<const unsigned*>(h->d_blob + h->cond_tab_off);
+    WN_HIP(h, hipMemsetAsync(x, 0, (size_t)B * L.XR * sizeof(float), st));
+    WN_HIP(h, hipMemsetAsync(flags, 0, ((size_t)h->num_cu * 16 + 1) * sizeof(unsigned), st));
+    const float* x0 = noise;
+    {
+        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+        if (noise) {
+            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
+        } else {
+            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
+                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
+            x0 = x0g;
+        }
+    }
+    wn_iaf_p_zero_pads(reinterpret_cast<unsigned*>(lbuf), L.RS, L.pipe_layers * 16, st);
+    if (c.share_deconv) {
+        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, true);
+        if (rc) return rc;
+        wn_iaf_c_cond(enc, h->d_blob, cond_tab, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T, h->num_cu, st);
+    }
+    const int max_blk = wn_iaf_r_max_cols(h) / 16, nblk_tot = (int)(L.T / 16);
+    unsigned epoch = 0;
+    double* unused = nullptr;
+    (void)unused;
+    for (int k = 0; k < c.n_flows; ++k) {
+        const IafFlowPack& fp = h->flows[k];
+        if (!c.share_deconv) {
+            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, true);
+            if (rc) return rc;
+            wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base, Cc, L.c_bstride, L.TE, L.c0, (int)fp.layers.size() + 1, B,
+                          L.T, h->num_cu, st);
+        }
+        const size_t row0 = c.share_deconv ? (size_t)fp.rb_base : 0;      // first row block of this flow inside C
+        const int nl = (int)fp.layers.size();
+        if (h->prof_on) {
+            hipEvent_t ev;
+            WN_HIP(h, hipEventCreate(&ev));
+            h->prof_events.push_back(ev);
+            WN_HIP(h, hipEventRecord(ev, st));
+        }
+        for (int b = 0; b < B; ++b) {
+            float* xb = x + (size_t)b * L.XR;
+            const float* Cb = Cc + (size_t)b * L.c_bstride + row0 * rb_floats;
+            wn_iaf_h_start(xb, h->d_blob + fp.start_off, lbuf, L.T, L.XR, L.RS, 1, st);
+            for (int b0 = 0; b0 < nblk_tot; b0 += max_blk) {
+                epoch += 256;
+                int rc = wn_iaf_r_flow(h, fp, Cb, (int64_t)rb_floats, reinterpret_cast<unsigned*>(lbuf), L.RS, 16 * b0,
+                                       std::min(max_blk, nblk_tot - b0), flags, epoch, st);
+                if (rc) return rc;
+                if (h->prof_on) ++h->prof_launches;
+            }
+            wn_iaf_c_head(lbuf + (size_t)nl * buf_floats, Cb + (size_t)nl * rb_floats, L.c_bstride, h->d_blob + fp.head_off_h,
+                          xb, Mt + (size_t)b * L.T, St + (size_t)b * L.T, L.RS, L.XR, L.T, k == 0 ? 1 : 0, 1, h->num_cu, st);
+        }
+        if (h->prof_on) {
+            hipEvent_t ev;
+            WN_HIP(h, hipEventCreate(&ev));
+            h->prof_events.push_back(ev);
+            WN_HIP(h, hipEventRecord(ev, st));
+        }
+    }
+    {
+        const int64_t nn = (int64_t)B * L.T;
+        const int Q = c.use_mu_law ? 256 : 65536;
+        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
+                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
+        wn_iaf_p_poison(flags + (size_t)h->num_cu * 16, wav, nn, st);
+        if (rand_out && rand_out != x0)
+            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    WN_HIP(h, hipGetLastError());
     return WN_OK;
 }
 
@@ -808,6 +921,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         if (rc) return rc;
         rc = wn_iaf_s_set_attrs(h);
         if (rc) return rc;
+        rc = wn_iaf_r_set_attrs(h);
+        if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_LAYER_FLOATS * sizeof(float)));
@@ -817,6 +932,8 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         h->iaf_attrs_set = true;
     }
 
+    if (L.form == WN_COND_RESHOIST)
+        return iaf_generate_reshoist(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
     if (L.form == WN_COND_RESIDENT)
         return iaf_generate_resident(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
     if (L.form == WN_COND_PIPE)
@@ -984,6 +1101,11 @@ int wn_iaf_form(const wn_handle* h, int B, int64_t T) {
     int mode = h->cfg.cond_mode;
     if (mode == WN_COND_AUTO) mode = h->cond_env_mode;           // WN_COND, resolved once in wn_create
     if (mode == WN_COND_PIPE) return wn_iaf_p_supported(h) ? WN_COND_PIPE : WN_COND_FUSED;
+    if (mode == WN_COND_RESHOIST) {
+        for (const IafFlowPack& fp : h->flows)
+            if (fp.layers.empty() || (int)fp.layers.size() > wn_iaf_r_max_layers()) return WN_COND_HOISTED;
+        return WN_COND_RESHOIST;
+    }
     if (mode == WN_COND_RESIDENT) {
         for (const IafFlowPack& fp : h->flows)
             if (fp.layers.empty() || (int)fp.layers.size() > wn_iaf_s_max_layers()) return WN_COND_FUSED;

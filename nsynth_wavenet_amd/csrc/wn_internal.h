@@ -157,6 +157,7 @@ constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB In
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
 constexpr int WN_COND_RESIDENT = 4; // every layer of a flow in ONE launch, activations resident per CU (wn_iaf_s.hip)
+constexpr int WN_COND_RESHOIST = 5; // hoisted GEMM + all layers of a flow in ONE launch per pass, activations resident per CU (wn_iaf_r.hip)
 constexpr int WN_COND_PIPE = 3;    // fused form, all layers and heads as ONE persistent pipeline launch (wn_iaf_p.hip)
 
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
@@ -226,6 +227,12 @@ int wn_iaf_p_run(wn_handle* h, const WnPipeBufs& P, int B0, int Bc, hipStream_t 
 void wn_iaf_p_zero_pads(unsigned* lbuf, int64_t RS, int rows, hipStream_t st);
 void wn_iaf_p_poison(const unsigned* err, float* wav, int64_t n, hipStream_t st);
 int wn_iaf_form(const wn_handle* h, int B, int64_t T);
+// ---- resident layers on hoisted conditioning (wn_iaf_r.hip) ----
+int wn_iaf_r_set_attrs(wn_handle* h);
+int wn_iaf_r_max_cols(const wn_handle* h);
+int wn_iaf_r_max_layers();
+int wn_iaf_r_flow(wn_handle* h, const IafFlowPack& fp, const float* C, int64_t rb_floats, unsigned* lbuf, int64_t RS,
+                  int col0, int nblk, unsigned* flags, unsigned epoch, hipStream_t st);
 // ---- segment-resident flow kernel (wn_iaf_s.hip) ----
 int wn_iaf_s_set_attrs(wn_handle* h);
 int wn_iaf_s_max_cols(const wn_handle* h);

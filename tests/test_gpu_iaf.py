@@ -25,7 +25,7 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f16x3-hoisted-resident', 'f32'])
 @pytest.mark.parametrize('tag', ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'])
 def test_golden_vectors(tag, precision):
     """HIP path vs the committed oracle vectors (shared deconv + centre crop 76; unit-gain
