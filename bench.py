@@ -187,6 +187,23 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
                 'frac': achieved_gbps / PEAK_HBM_GBPS,
                 'note': '768 B/sample/layer in this kernel + 256 B/sample/layer written by iaf_cond_h_kernel '
                         '(vs 1536 B/sample/layer of the fused layer kernel)'}
+    elif eng.precision in ('f16x3-resident', 'f16x3-hoisted-resident'):
+        # one launch = every layer of ONE flow over one pass; the event pairs bracket all such launches of a call:
+        # the layer-granular bytes of the whole residual stack over their summed time
+        nl = sum(eng.hp.num_iaf_layers)
+        per = LAYER_BYTES_PER_SAMPLE if eng.precision == 'f16x3-resident' else LAYER_BYTES_PER_SAMPLE_HOISTED
+        tot_b, tot_f = per * nl * B * T, LAYER_FLOP_PER_SAMPLE * nl * B * T
+        # launches of one call: flows x utterances x passes (a pass = 256 CUs x 128 or 192 resident columns)
+        per_call = len(eng.hp.num_iaf_layers) * B * -(-T // (256 * (128 if eng.precision == 'f16x3-resident' else 192)))
+        bytes_per_launch = tot_b / per_call
+        flops_per_launch = tot_f / per_call
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        achieved_tf = flops_per_launch / avg_layer_s / 1e12
+        kern = 'iaf_srf_kernel (all layers of a flow per launch, enc in registers, l in LDS)' if eng.precision == 'f16x3-resident' \
+            else 'iaf_res_kernel (all layers of a flow per launch on hoisted conditioning, l in LDS)'
+        roof = {'kernel': kern + ', split-fp16 MFMA; EXPERIMENTAL form', 'bound': 'hbm', 'achieved': achieved_gbps,
+                'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS}}
     elif eng.precision == 'f16x3-pipe':
         # ONE launch = every layer and head of the student; the fused form's bytes (1536 B per
         # sample and layer + 1296 B per head) over the launch time

@@ -1,19 +1,23 @@
 # final measurement pass of a round (run through gpurun): tests, bench lines, kernel stats, PMC passes
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
-timeout 300 python bench.py --no-cpu-baseline --precision f16x3-fused 2>&1 | tail -1 > gpurun_out/bench_f16x3_fused.json
-timeout 300 python bench.py --no-cpu-baseline --precision f32 2>&1 | tail -1 > gpurun_out/bench_f32.json
-timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --batch-per-gpu 8 2>&1 | tail -1 > gpurun_out/bench_f16x3_b8.json
+timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
+for p in f16x3-fused f16x3-pipe f16x3-resident f16x3-hoisted-resident f32; do
+  timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 5 --precision $p 2>&1 | tail -1 > gpurun_out/bench_$p.json
+done
+timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --batch-per-gpu 8 2>&1 | tail -1 > gpurun_out/bench_f16x3_b8.json
 for b in 1 8 64; do timeout 300 python bench_aux.py --workload ar --batch $b 2>&1 | tail -1 > gpurun_out/bench_ar_b$b.json; done
 timeout 300 python bench_aux.py --workload teacher 2>&1 | tail -1 > gpurun_out/bench_teacher.json
-bash scripts/pmc_layer.sh fin > gpurun_out/pmc_fin.log 2>&1
-bash scripts/pmc_layer.sh fused "--precision f16x3-fused" > gpurun_out/pmc_fused.log 2>&1
-bash scripts/pmc_layer.sh b8 "--batch-per-gpu 8" > gpurun_out/pmc_b8.log 2>&1
+bash scripts/pmc_layer.sh fin "--no-extras" > gpurun_out/pmc_fin.log 2>&1
+bash scripts/pmc_layer.sh fused "--no-extras --precision f16x3-fused" > gpurun_out/pmc_fused.log 2>&1
+bash scripts/pmc_layer.sh b8 "--no-extras --batch-per-gpu 8" > gpurun_out/pmc_b8.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin1 -o fin1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/fin1.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/finf -o finf -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --precision f16x3-fused > $R/gpurun_out/finf.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin1 -o fin1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/fin1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/finf -o finf -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --precision f16x3-fused > $R/gpurun_out/finf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
+for p in f16x3-pipe f16x3-resident f16x3-hoisted-resident; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin_$p -o fin -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --precision $p > /dev/null 2>&1
+done
 cd $R; for f in gpurun_out/bench_*.json; do python -c "
 import json; d=json.load(open('$f')); r=d['roofline']; print('$f', round(d['value']/1e6,3),'Ms/s', round(d['ms_per_step'],3),'ms', r['bound'], round(r['achieved'],1), round(r['frac'],3), r.get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done

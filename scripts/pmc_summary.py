@@ -1,9 +1,11 @@
-"""Build a profiles/r01_pmc_summary_*.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
+"""Build a profiles/rNN_pmc_summary_*.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
     python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json [batch_per_gpu] [bench args]
 Kernels are keyed by their base name; variants that do different work per launch keep their own key
 ("iaf_layer_h_kernel<first>": start conv fused in; "iaf_layer_c_kernel<head>": flow head in the epilogue;
 "iaf_pair_c_kernel<...>": per template arguments)."""
 import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nsynth_wavenet_amd import build as wbuild
 
 src, dst = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -45,11 +47,14 @@ for k, d in agg.items():
 out = {
     '_about': 'rocprofv3 --pmc passes (scripts/pmc_layer.sh: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass, instruction-mix '
               'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ' + extra + '`, one MI355X, '
-              'round 1, split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
+              'round 2, split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
               'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a coalesced '
               'stream, MI355X_MICROARCH.md; calibrated on iaf_head_h_kernel: it reads 98.3 MB exactly once and reports '
               '~48.8 MB). These fabric-side counters include Infinity Cache hits.',
     'workload': {'batch_per_gpu': batch, 'frames': 384, 'samples': 76800},
+    # hash of the kernel sources these counters were measured on (nsynth_wavenet_amd.build.source_hash): bench.py
+    # replays `hbm_bytes_per_launch` as roofline.traffic only while the sources it runs are the same
+    'source_hash': wbuild.source_hash(),
     'kernels': kernels,
 }
 json.dump(out, open(dst, 'w'), indent=1)
