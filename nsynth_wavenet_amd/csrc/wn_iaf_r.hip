@@ -1,5 +1,5 @@
-// Residual layers of a flow on HOISTED conditioning with the activations resident per CU: one launch runs every
-// layer of the flow over a pass of <= 256 x 128 columns.
+// Residual layers of a flow on HOISTED conditioning with the activations resident per CU (EXPERIMENTAL, precision
+// 'f16x3-hoisted-resident'): one launch runs every layer of the flow over a pass of <= 256 x 192 columns.
 //
 //   wavenet/parallel_wavenet.py:227-254 (residual layers), masked.py:160-232 (causal dilated conv); the
 //   conditioning 1x1 of every layer comes from the GEMM of wn_iaf_c.hip (`C`, Fastgen.cond_vars' precedent).
@@ -8,7 +8,7 @@
 // 1x1), different data movement.  With one launch per layer a 4.8 s utterance gives every wave 2-3 blocks of 16
 // columns per launch: the launch is a latency chain (load taps from the fabric, compute, store, launch boundary)
 // and reaches 0.40 of the HBM roofline.  Here
-//   * workgroup c (one per CU, EIGHT waves = two per SIMD, one block of 16 columns each) owns 128 columns of the
+//   * workgroup c (one per CU, TWELVE waves = three per SIMD, one block of 16 columns each) owns 192 columns of the
 //     pass and keeps their residual stream `l` in LDS (two buffers, read / write) through all layers;
 //   * the taps t-d, t-2d that fall inside the segment are LDS reads; the ones left of it are read from the global
 //     buffer of the previous layer, which every workgroup also writes (write-once, write-through `sc1` stores)
@@ -16,10 +16,19 @@
 //     CDNA4 guide; every spin is bounded and a wave only ever waits for LOWER-numbered workgroups;
 //   * the dilated-conv fragments (48 KB) and the residual fragments (8 KB) of the next layer arrive in LDS by
 //     LDS-DMA while the current layer computes;
-//   * with two waves per SIMD the hardware overlaps one wave's gate / split arithmetic (VALU) with the other
+//   * with three waves per SIMD the hardware overlaps one wave's gate / split arithmetic (VALU) with the other
 //     wave's MFMAs -- the overlap a single 512-register wave per SIMD cannot get from the compiler.
 // Fabric traffic per sample and layer: the C tile (256 B, read once, non-temporal), `l` written once (256 B) and
 // the halo columns read back; no tap re-reads, no launch floor per layer.
+//
+// Measured on MI355X (config 2, one utterance): correct (golden vectors); the eight launches of a call take 954 us
+// against 1 014 us for the 52 layer launches of the default form, the whole call 1.61 ms against 1.57 ms (the
+// separate start-conv and head launches eat the difference).  A layer-pass costs ~15k cycles (WN_RES_DEBUG prints
+// the stamps): ~4.6k in the K loop (three waves per SIMD share the matrix pipe: 3.5k of MFMA issue), ~3.6k in the
+// epilogue (all waves in their VALU phase at once: the barrier between K loop and epilogue -- needed because the
+// fragment buffer is re-filled under the epilogue -- puts the waves in lockstep, so VALU and MFMA phases do not
+// overlap across waves either), 2-4k waiting for the left neighbour's progress word (a flag hop is ~1.5-2 us
+// under load) and ~2.5k in acknowledgement waits and barriers.  Not the default; see DESIGN.md section 3.7.
 #include <algorithm>
 #include <cstdlib>
 
@@ -96,7 +105,7 @@ __device__ inline bool wait_left(rsrc_t rf, rsrc_t rerr, int c, int nn, unsigned
             const unsigned v = ld1_sc1(rf, off);
             const bool ok = !valid || (int)(v - need) >= 0;          // progress words only grow inside a call
             if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (spins > 64u) __builtin_amdgcn_s_sleep(1);          // the first polls go back to back: a hop is ~1 us
             if ((spins & 255u) == 255u) {
                 if (__builtin_amdgcn_readfirstlane(ld1_sc1(rerr, 0)) != 0) return false;
                 if (spins > SPIN_LIMIT) {
@@ -196,11 +205,9 @@ __global__ __launch_bounds__(64 * RW, 1) void iaf_res_kernel(const ResArgs A) {
         const float* br = bg + 64;
         const bool has_next = j + 1 < A.nlayers;
 
-        if (j > 0) dma(j, IAF_P_FLOATS, prw, IAF_PR_FLOATS);       // residual fragments: land during the K loop
         f4 acc[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[mb] = cn[mb];
-        if (has_next) c_tile(j + 1, cn);                            // next layer's C tile: a whole layer ahead
         if (mine) {
             // left neighbours whose layer j-1 output I read: columns [seg_col + 16 wave - 2d, seg_col) of buffer j
             if (j > 0 && c > 0) {
@@ -226,13 +233,25 @@ __global__ __launch_bounds__(64 * RW, 1) void iaf_res_kernel(const ResArgs A) {
                     rl[tp][sx] = buf_ld4<SC1>(rin, vo, (8 + 4 * sx) * RS16);
                 }
             }
+            // only now the bulk prefetches: a progress poll queues behind whatever this CU has in flight
+            if (j > 0) dma(j, IAF_P_FLOATS, prw, IAF_PR_FLOATS);   // residual fragments: land during the K loop
+            if (has_next) c_tile(j + 1, cn);                        // next layer's C tile: a whole layer ahead
             constexpr int ORD[6] = {4, 5, 2, 3, 0, 1};
             wn_u4 a[2][4][2];
+            wn_u4 bh[2], bl[2];                                     // B operand of the current / next K-step
+            auto tap_b = [&](int ks, wn_u4& h_, wn_u4& l_) {
+                const int tp = ks >> 1, sx = ks & 1;
+                const int src = lc - (2 - tp) * d;
+                const int lsrc = src < 0 ? 0 : src;
+                h_ = *reinterpret_cast<const wn_u4*>(lrd + (4 * sx + q) * LROW + lsrc * 16);
+                l_ = *reinterpret_cast<const wn_u4*>(lrd + (8 + 4 * sx + q) * LROW + lsrc * 16);
+            };
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 a[0][mb][0] = Pl[((ORD[0] * 4 + mb) * 2 + 0) * 64];
                 a[0][mb][1] = Pl[((ORD[0] * 4 + mb) * 2 + 1) * 64];
             }
+            tap_b(ORD[0], bh[0], bl[0]);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int ks = ORD[i], tp = ks >> 1, sx = ks & 1;
@@ -242,23 +261,22 @@ __global__ __launch_bounds__(64 * RW, 1) void iaf_res_kernel(const ResArgs A) {
                         a[(i + 1) & 1][mb][0] = Pl[((ORD[i + 1] * 4 + mb) * 2 + 0) * 64];
                         a[(i + 1) & 1][mb][1] = Pl[((ORD[i + 1] * 4 + mb) * 2 + 1) * 64];
                     }
+                    tap_b(ORD[i + 1], bh[(i + 1) & 1], bl[(i + 1) & 1]);
                 }
-                const int src = lc - (2 - tp) * d;
-                const int lsrc = src < 0 ? 0 : src;
-                wn_u4 bh = *reinterpret_cast<const wn_u4*>(lrd + (4 * sx + q) * LROW + lsrc * 16);
-                wn_u4 bl = *reinterpret_cast<const wn_u4*>(lrd + (8 + 4 * sx + q) * LROW + lsrc * 16);
+                wn_u4 ch_ = bh[i & 1], cl_ = bl[i & 1];
                 if (tp < 2) {
-                    const bool remote = src < 0;
+                    const bool remote = lc - (2 - tp) * d < 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        bh[e] = remote ? rh[tp][sx][e] : bh[e];
-                        bl[e] = remote ? rl[tp][sx][e] : bl[e];
+                        ch_[e] = remote ? rh[tp][sx][e] : ch_[e];
+                        cl_[e] = remote ? rl[tp][sx][e] : cl_[e];
                     }
                 }
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma3(a[i & 1][mb][0], a[i & 1][mb][1], bh, bl, acc[mb]);
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma3(a[i & 1][mb][0], a[i & 1][mb][1], ch_, cl_, acc[mb]);
             }
         }
+        if (!mine && j > 0) dma(j, IAF_P_FLOATS, prw, IAF_PR_FLOATS);
         STAMP(2);
         // everybody is done with the dilated fragments of layer j (replaced under the epilogue); the residual
         // fragments of layer j have landed

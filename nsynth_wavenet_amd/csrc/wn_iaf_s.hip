@@ -1,5 +1,6 @@
-// "Segment-resident" form of the IAF residual stack: ONE launch runs every layer of a flow over a span of
-// time, with the activations of a time segment living on the CU that owns it.
+// "Segment-resident" form of the IAF residual stack (EXPERIMENTAL, precision 'f16x3-resident'): ONE launch runs
+// every layer of a flow over a pass of time, with the activations AND the upsampled mel of a time segment living on
+// the CU that owns it.
 //
 //   wavenet/parallel_wavenet.py:227-254 (residual layers of one flow), masked.py:160-232 (causal dilated conv).
 //
@@ -8,25 +9,33 @@
 // the fabric -- ~5 GB per utterance at the ~6 TB/s an XCD fabric port delivers -- and pays a launch floor and a
 // tile round-off 60 times.  Here nothing of that crosses the fabric twice:
 //
-//   * workgroup c (one per CU, 4 waves) owns the columns [a_c, a_c + S_c) of a PASS (<= 192 columns per CU,
-//     <= 3 blocks of 16 columns per wave); it runs ALL layers of the flow on them, layer after layer;
-//   * the upsampled mel of the segment (`enc`, 1 KB per column) is loaded ONCE per launch into registers --
-//     it is the MFMA B operand of the conditioning 1x1 of every layer (192 VGPRs per lane);
-//   * the residual stream `l` of the segment lives in LDS (two buffers of 192 columns x 256 B, read / write);
-//   * the weights of the dilated conv and of the residual 1x1 (57 KB per layer) are staged in LDS once per layer,
-//     the conditioning weights (64 KB per layer) stream from L2 as MFMA A operands, one K-step ahead;
+//   * workgroup c (one per CU, 4 waves) owns a contiguous segment of the pass (NBW blocks of 16 columns per wave,
+//     template parameter 2 or 3); it runs ALL layers of the flow on them, layer after layer;
+//   * the upsampled mel of the segment (`enc`, 1 KB per column) is loaded ONCE per launch into registers -- it is
+//     the MFMA B operand of the conditioning 1x1 of every layer (64 registers per block and lane; the compiler
+//     keeps them in AGPRs);
+//   * the residual stream `l` of the segment lives in LDS (two buffers, read / write);
+//   * the dilated-conv fragments (48 KB) and the residual fragments (8 KB) of a layer arrive in LDS by LDS-DMA
+//     (global_load_lds_dwordx4, no registers) under the previous phase; the conditioning weights (64 KB per
+//     layer) stream from L2 as MFMA A operands;
 //   * a layer's output is ALSO written to a global buffer of its own (write-once, write-through `sc1` stores):
 //     the causal taps t-d, t-2d that fall LEFT of the segment are read from there -- the left neighbours'
 //     columns -- after those neighbours published "layer j done" in a per-wave progress word (same R1 hand-off
 //     as wn_iaf_p.hip; every spin is bounded).  A wave only ever waits for LOWER-numbered workgroups.
-//   * the conditioning K-steps of a layer do not depend on `l`: they run first and hide the neighbours'
-//     publish latency; the dilated K-steps and the epilogue follow.
+//   * software pipeline over layers: the conditioning K-steps of layer j+1 (MFMA, depend on nothing layer j
+//     produces) are issued in the same region as the epilogue of layer j (VALU).
 //
-// Fabric traffic per sample and layer: 256 B written (+ the few halo columns read back), `enc` once per launch
-// instead of once per layer, no projected-term workspace: the launch is bound by the fp16 matrix pipe.
+// Measured on MI355X (config 2, one utterance): correct (golden vectors), but NOT faster than the default form --
+// 1.61 ms per call in its first, un-pipelined version (three blocks per wave), 2.2 ms in this one.  Where the
+// cycles go (WN_SRF_DEBUG=<workgroup> prints s_memtime stamps per layer): the conditioning A fragments are read by
+// all four waves of a CU through its one 64 B/clk L1 path (256 KB per layer: ~4k cycles against ~3k cycles of
+// MFMA work for two blocks per wave), the gate / split epilogue costs ~2.6k cycles per block and does not overlap
+// with MFMAs inside one 512-register wave (the compiler keeps the two streams apart; with three blocks per wave
+// the fused region spills and collapses), and every layer pays two workgroup barriers plus a neighbour hand-off.
+// Kept as a tested form and as the record of that measurement; see DESIGN.md section 3.7.
 //
-// A launch covers one flow, one utterance and one pass (a span of <= 256 x 192 columns); longer utterances
-// take several passes, left to right (a pass reads the previous passes' columns like any left neighbour).
+// A launch covers one flow, one utterance and one pass; longer utterances take several passes, left to right
+// (a pass reads the previous passes' columns like any left neighbour).
 #include <algorithm>
 #include <cstdlib>
 
@@ -186,14 +195,6 @@ __global__ __launch_bounds__(256, 1) void iaf_srf_kernel(const SrfArgs A) {
     constexpr int FR_PER_THREAD = IMG_A_WORDS / 4 / 256;        // 12
     auto frag_dma = [&](int jj) {
         const unsigned* src = reinterpret_cast<const unsigned*>(A.blob) + A.layers[jj].w_off;
-#ifdef WN_SRF_NO_DMA
-        wn_u4 t[FR_PER_THREAD];
-#pragma unroll
-        for (int i = 0; i < FR_PER_THREAD; ++i) t[i] = reinterpret_cast<const wn_u4*>(src)[i * 256 + threadIdx.x];
-#pragma unroll
-        for (int i = 0; i < FR_PER_THREAD; ++i) reinterpret_cast<wn_u4*>(frag)[i * 256 + threadIdx.x] = t[i];
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < FR_PER_THREAD; ++i) {
             const unsigned* g = src + (size_t)(i * 256 + wave * 64 + lane) * 4;
@@ -376,9 +377,7 @@ __global__ __launch_bounds__(256, 1) void iaf_srf_kernel(const SrfArgs A) {
         STAMP(3);
         wn_u4 ftl = (wn_u4){0u, 0u, 0u, 0u};
         if (has_next) {
-#ifndef WN_SRF_NO_DMA
             frag_dma(j + 1);
-#endif
             ftl = tail_load(j + 1);
         }
         if (cnt > 0) {
@@ -464,21 +463,9 @@ __global__ __launch_bounds__(256, 1) void iaf_srf_kernel(const SrfArgs A) {
                     }
                 }
             }
-            // desired issue order of the region: one MFMA, then four VALU instructions, 12 * NBW * 9 times
-            // (8 conditioning K-steps + the residual 1x1); loads, LDS accesses and stores float
-#ifdef WN_SRF_PATTERN
-#pragma unroll
-            for (int r = 0; r < 12 * NBW * 9; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-#endif
         }
         STAMP(4);
         if (has_next) tail_store(j + 1, ftl);
-#ifdef WN_SRF_NO_DMA
-        if (has_next) frag_dma(j + 1);
-#endif
         // every global access of this layer is older than the fragment loads that just came back: the stores
         // of layer j have been acknowledged (vmcnt retires in issue order) -> publish "j + 1 layers done"
         WN_WAIT_VM0();
