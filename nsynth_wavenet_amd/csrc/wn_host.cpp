@@ -102,6 +102,9 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
     if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_RESHOIST)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
+    if (c.cond_mode == WN_COND_RESHOIST && !getenv("WN_UNVERIFIED_FORMS"))
+        return wn_fail(nullptr, WN_EINVAL, "config: conditioning mode 5 (hoisted-resident) is withheld: it is not parity-clean "
+                       "(wn_iaf_r.hip header); set WN_UNVERIFIED_FORMS=1 to run it for investigation");
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)
             return wn_fail(nullptr, WN_EINVAL, "config: the IAF kernels tile time in 64-sample blocks and need "
@@ -167,7 +170,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         else if (!strcmp(e, "hoisted")) h->cond_env_mode = WN_COND_HOISTED;
         else if (!strcmp(e, "pipe")) h->cond_env_mode = WN_COND_PIPE;
         else if (!strcmp(e, "resident")) h->cond_env_mode = WN_COND_RESIDENT;
-        else if (!strcmp(e, "hoisted-resident")) h->cond_env_mode = WN_COND_RESHOIST;
+        else if (!strcmp(e, "hoisted-resident") && getenv("WN_UNVERIFIED_FORMS")) h->cond_env_mode = WN_COND_RESHOIST;
     }
     h->frame_shift = 1;
     for (int j = 0; j < cfg->n_deconv; ++j) h->frame_shift *= cfg->deconv_stride[j];

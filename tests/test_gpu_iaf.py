@@ -25,7 +25,15 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f16x3-hoisted-resident', 'f32'])
+def test_withheld_form_is_refused(monkeypatch):
+    """cond_mode 5 (hoisted-resident) is not parity-clean: wn_create must refuse it by default."""
+    from nsynth_wavenet_amd.engine import Engine
+    monkeypatch.delenv('WN_UNVERIFIED_FORMS', raising=False)
+    with pytest.raises(Exception, match='withheld'):
+        Engine(load_json('parallel_wavenet.json'), precision='f16x3-hoisted-resident')
+
+
+@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f32'])
 @pytest.mark.parametrize('tag', ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'])
 def test_golden_vectors(tag, precision):
     """HIP path vs the committed oracle vectors (shared deconv + centre crop 76; unit-gain
