@@ -170,6 +170,19 @@ int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F,
 int wn_clip_quant(wn_handle* h, const float* x, int64_t n,
                   float* wav, int32_t* idx, void* stream);
 
+/* ---- log-mel featuriser of the generation drivers (auxilaries/mel_extractor.py:31-44 melspectrogram,
+ * :65-90 stft / mel basis / amp_to_db / normalise; called by eval_wavenet.py / eval_parallel_wavenet.py on the
+ * host through librosa).  Needs no model handle; errors are reported through wn_last_error(NULL). ---- */
+
+/* Frames of an utterance of n_samples: 1 + n_samples / 200 (centred frames, hop 12.5 ms at 16 kHz). */
+int64_t wn_mel_frames(int64_t n_samples);
+
+/* wav [B][L] float32 (device) -> mel [B][wn_mel_frames(L)][80] float32 (device), values in [0, 1]:
+ * reflect-padded centred 2048-point frames, periodic Hann window of 800 samples, |STFT|, Slaney mel basis
+ * (80 bands, 125-7600 Hz), 20 log10(max(1e-5, .)), clip((S + 140) / 140, 0, 1).  L must exceed 1024 (the reflect
+ * padding, as in numpy.pad). */
+int wn_mel_spectrogram(const float* wav, int B, int64_t L, float* mel, void* stream);
+
 /* ---- autoregressive path (wavenet.py:379-514, fastgen.py:118-169) ---- */
 
 /* Number of injected random values per sample and per batch element:

@@ -17,7 +17,7 @@ ERRNAMES = {-22: 'WN_EINVAL', -2: 'WN_ENOENT', -12: 'WN_ENOMEM', -5: 'WN_EIO', -
 SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_iaf_length',
            'wn_ar_length', 'wn_workspace_bytes', 'wn_deconv', 'wn_iaf_generate', 'wn_clip_quant',
            'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph',
-           'wn_iaf_cond_hoisted', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_last_error', 'wn_destroy']
+           'wn_iaf_cond_hoisted', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
 
 
 class WnConfig(ctypes.Structure):
@@ -81,6 +81,9 @@ def load():
     lib.wn_profile_begin.argtypes = [vp]
     lib.wn_profile_pause.argtypes = [vp, c.c_int]
     lib.wn_profile_end.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]
+    lib.wn_mel_frames.argtypes = [i64]
+    lib.wn_mel_frames.restype = i64
+    lib.wn_mel_spectrogram.argtypes = [vp, c.c_int, i64, vp, vp]
     lib.wn_last_error.argtypes = [vp]
     lib.wn_last_error.restype = c.c_char_p
     lib.wn_destroy.argtypes = [vp]

@@ -7,9 +7,9 @@ samples centred in the FFT frame, reflect-padded centred frames; Slaney-scale,
 area-normalised triangular mel filterbank (80 bands, 125-7600 Hz) applied to the
 MAGNITUDE; 20*log10(max(1e-5, .)); clip((S + 140) / 140, 0, 1); time-major output.
 `preemphasis` and `ref_level_db` are declared by the reference but never applied.
-`melspectrogram` / `batch_melspectrogram` are host numpy; `batch_melspectrogram_device` is the same
-featuriser on the GPU (rocFFT through torch.stft + one matmul), so that wav -> mel -> audio stays on
-the device in the CLIs.
+`melspectrogram` / `batch_melspectrogram` are host numpy (the reference's own host-side form);
+`batch_melspectrogram_device` is the same featuriser as a HIP kernel behind the C ABI (`wn_mel_spectrogram`,
+csrc/wn_mel.hip), so that wav -> mel -> audio stays on the device in the CLIs.
 """
 import numpy as np
 
@@ -86,25 +86,20 @@ def batch_melspectrogram(y):
     return np.array([melspectrogram(y[b]) for b in range(y.shape[0])])
 
 
-_dev_cache = {}
-
-
 def batch_melspectrogram_device(y, device=None):
-    """[B, L] float audio (numpy or torch) -> [B, 1 + L // 200, 80] float32 mel ON THE GPU.
-    Same definition as `melspectrogram` (centred reflect-padded frames, periodic Hann 800 in a
-    2048-point FFT, magnitude, Slaney mel, dB, normalise); differences are float32 rounding."""
+    """[B, L] float audio (numpy or torch) -> [B, 1 + L // 200, 80] float32 mel ON THE GPU, through the C ABI
+    (`wn_mel_spectrogram`, csrc/wn_mel.hip: a hand-written HIP kernel, no FFT library).  Same definition as
+    `melspectrogram` (centred reflect-padded frames, periodic Hann 800 in a 2048-point DFT, magnitude, Slaney mel,
+    dB, normalise); differences are float32 rounding.  There is no CPU fallback: without libwnhip.so this raises."""
     import torch
+    from .. import _lib
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
-    y = torch.as_tensor(y, dtype=torch.float32, device=dev)
-    assert y.dim() == 2
-    key = str(dev)
-    if key not in _dev_cache:
-        _dev_cache[key] = (torch.hann_window(WIN_LENGTH, periodic=True, dtype=torch.float32, device=dev),
-                           torch.from_numpy(mel_filterbank()).to(dev))
-    win, basis = _dev_cache[key]
-    spec = torch.stft(y, n_fft=N_FFT, hop_length=FRAME_SHIFT, win_length=WIN_LENGTH, window=win, center=True,
-                      pad_mode='reflect', return_complex=True)                 # [B, 1025, frames]
-    S = torch.matmul(basis, spec.abs())                                         # [B, 80, frames]
-    S = 20.0 * torch.log10(torch.clamp(S, min=MIN_AMP))
-    NS = torch.clamp((S - MIN_LEVEL_DB) / -MIN_LEVEL_DB, 0.0, 1.0)
-    return NS.transpose(1, 2).contiguous()
+    y = torch.as_tensor(y, dtype=torch.float32, device=dev).contiguous()
+    if y.dim() != 2:
+        raise ValueError('batch_melspectrogram_device: expected [B, L] audio, got shape {}'.format(tuple(y.shape)))
+    lib = _lib.load()
+    B, L = int(y.shape[0]), int(y.shape[1])
+    with torch.cuda.device(dev):
+        out = torch.empty(B, int(lib.wn_mel_frames(L)), NUM_MEL, dtype=torch.float32, device=dev)
+        _lib.check(lib.wn_mel_spectrogram(y.data_ptr(), B, L, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return out

@@ -33,6 +33,10 @@
 #ifndef WN_C_LD_AUX
 #define WN_C_LD_AUX 2
 #endif
+// Cache policy of the residual-stream stores of the layer kernels (aux: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#ifndef WN_L_ST_AUX
+#define WN_L_ST_AUX 0
+#endif
 #ifndef WN_ENC_STAGE_AUX
 #define WN_ENC_STAGE_AUX 0
 #endif
@@ -197,12 +201,29 @@ struct HeadArgs {
     int first;
 };
 
+#ifdef WN_LC_STAMPS      // dev aid: s_memtime stamps (10 ns units) of wave 0 of a few workgroups of the layer kernel
+__device__ unsigned long long wn_lc_stamp_buf[8][16];
+#define LC_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8 && (i) < 16)           \
+            wn_lc_stamp_buf[blockIdx.x >> 6][(i)] = __builtin_amdgcn_s_memtime();                      \
+    } while (0)
+#else
+#define LC_STAMP(i) do {} while (0)
+#endif
+
 template <int HN, bool LAST = false>
 __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
     const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int TILE = 64 * HN;
+    LC_STAMP(0);
+#ifdef WN_LC_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8) wn_lc_stamp_buf[blockIdx.x >> 6][13] = __builtin_amdgcn_s_memrealtime();
+#endif
+    int stamp_i = 3;
+    (void)stamp_i;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
@@ -298,6 +319,8 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
                     acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        LC_STAMP(stamp_i);
+        ++stamp_i;
         // epilogue per column block: gate, residual 1x1, split, store
         const __amdgpu_buffer_rsrc_t ro =
             __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
@@ -346,8 +369,8 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
             if (!LAST) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    buf_st4(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
-                    buf_st4(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
+                    buf_st4<WN_L_ST_AUX>(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
+                    buf_st4<WN_L_ST_AUX>(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
                 }
             } else {
                 // ---- flow head on this column block (same arithmetic as iaf_head_c_kernel) ----
@@ -396,12 +419,15 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
                 }
             }
         }
+        LC_STAMP(stamp_i);
+        ++stamp_i;
     };
 
     KOp<HN> bA[6], bB[6];
     f4 cA[4][HN], cB[4][HN], hA[4][HN], hB[4][HN];
     int tile = tw.first;
     if (tile < tend) load_tile(tile, bA, cA, hA);
+    LC_STAMP(1);
     // the weight image is staged AFTER the first tile's operand loads are in flight
     stage_words<LC_A_WORDS>(wpack, ldsw);
     stage_words<LC_TAIL_WORDS>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
@@ -414,6 +440,7 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
     }
     inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
     inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
+    LC_STAMP(2);
     while (tile < tend) {
         body(tile, bA, cA, hA, bB, cB, hB);
         tile += tstep;
@@ -421,6 +448,14 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
         body(tile, bB, cB, hB, bA, cA, hA);
         tile += tstep;
     }
+#ifdef WN_LC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LC_STAMP(stamp_i);
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8) {
+        wn_lc_stamp_buf[blockIdx.x >> 6][15] = (unsigned long long)stamp_i;
+        wn_lc_stamp_buf[blockIdx.x >> 6][14] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------- two residual layers in one launch (small dilations) ----------------
@@ -683,8 +718,8 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                 const int vo_out = lane_l + 16 * k * 16;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    buf_st4(qh[s2], ro, vo_out, (4 * s2) * RS16);
-                    buf_st4(ql[s2], ro, vo_out, (8 + 4 * s2) * RS16);
+                    buf_st4<WN_L_ST_AUX>(qh[s2], ro, vo_out, (4 * s2) * RS16);
+                    buf_st4<WN_L_ST_AUX>(ql[s2], ro, vo_out, (8 + 4 * s2) * RS16);
                 }
             }
 #pragma unroll
@@ -897,6 +932,24 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
                        tiles_per_row, ntiles, HeadArgs{});
+#ifdef WN_LC_STAMPS
+    static int dumped = 0;
+    if (dumped < 400 && getenv("WN_LC_DUMP")) {
+        ++dumped;
+        unsigned long long hb[8][16];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(wn_lc_stamp_buf), sizeof(hb));
+        if (dumped % 57 == 30)       // a few launches of a warm call
+            for (int w = 0; w < 8; ++w) {
+                const int ns = (int)hb[w][15];
+                fprintf(stderr, "lc d=%d hn=%d grid=%d wg %3d: issue %5.2f stage %5.2f |", d, hn, grid, w * 64,
+                        (double)(hb[w][1] - hb[w][0]) * 0.01, (double)(hb[w][2] - hb[w][1]) * 0.01);
+                for (int i = 3; i <= ns && i < 13; ++i) fprintf(stderr, " %5.2f", (double)(hb[w][i] - hb[w][i - 1]) * 0.01);
+                const double ticks = (double)(hb[w][ns < 13 ? ns : 12] - hb[w][0]), us = (double)(hb[w][14] - hb[w][13]) * 0.01;
+                fprintf(stderr, " | total %5.2f (x100 ticks) = %5.2f us by the 100 MHz counter => %4.0f MHz\n", ticks * 0.01, us, ticks / us);
+            }
+    }
+#endif
 }
 
 // Last layer of a flow with the flow head in its epilogue (64-sample tiles, two workgroups per CU).

@@ -53,8 +53,6 @@ constexpr int NBW_MAX = 3;                     // blocks of 16 columns per wave 
 constexpr int IMG_A_WORDS = 6 * 2048;          // dilated-conv fragments, K-steps 0-5
 constexpr int IMG_TAIL_WORDS = IAF_PR_FLOATS + 128 + 4;   // residual 1x1 fragments | biases | 1/scales
 constexpr int IMG_WORDS = IMG_A_WORDS + IMG_TAIL_WORDS;   // 14 468 words = 57 872 B
-constexpr int IMG_V4 = IMG_WORDS / 4;          // 3 617 16-byte words
-constexpr int IMG_PER_THREAD = (IMG_V4 + 255) / 256;      // 15
 static_assert(IMG_WORDS % 4 == 0, "");
 // LDS: two `l` buffers | dilated fragments | residual fragments | two bias tails
 constexpr int srf_lds_bytes(int nbw) { return 2 * 16 * (16 * 4 * nbw) * 16 + IMG_A_WORDS * 4 + IAF_PR_FLOATS * 4 + 2 * 132 * 4; }

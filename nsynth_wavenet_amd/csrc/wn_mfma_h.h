@@ -86,8 +86,9 @@ template <int AUX = 0>
 __device__ inline wn_u4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
 }
 
 

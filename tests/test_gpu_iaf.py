@@ -387,7 +387,8 @@ def test_resize_conv_upsampler(precision):
 
 
 def test_device_mel_featuriser_against_analysis():
-    """auxilaries/mel_extractor.py on the GPU (rocFFT + one matmul) against CLOSED FORMS -- two stationary tones
+    """auxilaries/mel_extractor.py on the GPU (wn_mel_spectrogram, the HIP kernel of csrc/wn_mel.hip, through the
+    C ABI) against CLOSED FORMS -- two stationary tones
     (the Hann window's DTFT at the bin offsets) and a unit impulse (the window sample, flat over frequency) --
     and against the float64 oracle featuriser (oracle/mel_np.py, explicit DFT) on noise, incl. the reference
     fixture length (154 480 samples -> 773 frames).  The host featuriser has the same test in tests/test_mel.py."""
@@ -415,6 +416,20 @@ def test_device_mel_featuriser_against_analysis():
     assert tuple(long.shape) == (2, 773, 80)
     host = M.batch_melspectrogram(wavs)                              # the product's two implementations agree as well
     assert np.abs(got - host).max() <= 2e-4
+    # ragged frame counts (the last workgroup of a row is partly filled), both edges reflect-padded, on the oracle
+    for L in (1025, 1799, 3000, 3200):
+        y = rs.uniform(-0.5, 0.5, [3, L]).astype(np.float32)
+        d = M.batch_melspectrogram_device(y)
+        assert tuple(d.shape) == (3, 1 + L // 200, 80)
+        for r in range(3):
+            assert np.abs(_np(d[r]).astype(np.float64) - OM.melspectrogram(y[r])).max() < 2e-4
+    # determinism, torch input on the device, error behaviour of numpy.pad(reflect) for too short signals
+    yt = torch.as_tensor(wavs, device='cuda')
+    assert torch.equal(M.batch_melspectrogram_device(yt), dev)
+    with pytest.raises(ValueError, match='1024'):
+        M.batch_melspectrogram_device(np.zeros([1, 1024], np.float32))
+    with pytest.raises(ValueError):
+        M.batch_melspectrogram_device(np.zeros([800], np.float32))
 
 
 def test_full_size_batch8_hoisted_conditioning():

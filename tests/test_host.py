@@ -35,6 +35,20 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert _lib.load().wn_abi_version() == 1
 
 
+def test_mel_entry_points_validate_arguments_before_touching_a_device():
+    """wn_mel_frames is the reference's frame count (1 + n // 200, librosa centred frames, hop 12.5 ms);
+    wn_mel_spectrogram refuses null pointers and signals that numpy.pad(reflect) would refuse (<= 1024 samples)."""
+    lib = _lib.load()
+    assert [lib.wn_mel_frames(n) for n in (0, 199, 200, 76800, 154480)] == [1, 1, 2, 385, 773]
+    assert lib.wn_mel_frames(-1) == -1
+    buf = (ctypes.c_float * 2048)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.wn_mel_spectrogram(None, 1, 2048, p, None) == -22
+    assert lib.wn_mel_spectrogram(p, 0, 2048, p, None) == -22
+    assert lib.wn_mel_spectrogram(p, 1, 1024, p, None) == -22
+    assert b'1024' in lib.wn_last_error(None)
+
+
 def test_wn_config_struct_matches_header_layout():
     # 7 scalars + 2*4 + 4 scalars + 8 + 7 scalars + 8 reserved = 42 int32
     assert ctypes.sizeof(_lib.WnConfig) == 4 * (7 + 4 + 4 + 4 + 8 + 7 + 8)
