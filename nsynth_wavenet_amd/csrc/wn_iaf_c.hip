@@ -37,6 +37,12 @@
 #ifndef WN_L_ST_AUX
 #define WN_L_ST_AUX 0
 #endif
+// Ablation switches of the conditioning GEMM (measurement only, results are WRONG when set; scripts/ablate_cond.sh):
+// 1 no C stores, 2 no enc staging loads, 4 A fragments loaded once per row block, 8 B operands read once per row block,
+// 16 one MFMA per product instead of three
+#ifndef WN_CK_ABL
+#define WN_CK_ABL 0
+#endif
 #ifndef WN_ENC_STAGE_AUX
 #define WN_ENC_STAGE_AUX 0
 #endif
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             for (int c4 = 0; c4 < 64 / RP / 4; ++c4) {
                 wn_u4 tmp[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) tmp[p] = buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
+                for (int p = 0; p < 4; ++p)
+                    tmp[p] = (WN_CK_ABL & 2) ? (wn_u4){(unsigned)p, 0u, 0u, 0u} : buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_NC + col] = tmp[p];
             }
@@ -131,9 +138,11 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             wn_u4 bb[2][2];
             bb[0][0] = Bt[q * CK_NC + n];
             bb[0][1] = Bt[(32 + q) * CK_NC + n];
+            __builtin_amdgcn_sched_barrier(0);     // not part of the first K-step's (2 LDS reads, 12 MFMAs) groups
             auto store_nb = [&](int nb) {
                 // column blocks past the end of the row fall outside the descriptor and are dropped
                 const int cb = (CK_NC / 16) * j + nb;
+                if ((WN_CK_ABL & 1) && acc[0][nb][0] != 12345.678f) return;      // keeps the accumulators live
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,
@@ -143,27 +152,45 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             for (int ks = 0; ks < 8; ++ks) {
                 // next K-step's fragments (the next row block's first ones at the end)
                 const int an1 = ks + 1 < 8 ? ao + (ks + 1) * 8 * 1024 : an;
+                if (!(WN_CK_ABL & 4) || ks == 7) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
-                    a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
+                    for (int mb = 0; mb < 4; ++mb) {
+                        a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
+                        a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
+                    }
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        a[(ks + 1) & 1][mb][0] = a[ks & 1][mb][0];
+                        a[(ks + 1) & 1][mb][1] = a[ks & 1][mb][1];
+                    }
                 }
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb) {
                     const int cur = nb & 1;
                     if (ks * 8 + nb + 1 < 64) {
                         const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
-                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
-                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                        if (WN_CK_ABL & 8) {
+                            bb[cur ^ 1][0] = bb[cur][0];
+                            bb[cur ^ 1][1] = bb[cur][1];
+                        } else {
+                            bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                            bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                        }
                     }
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
+                    if (!(WN_CK_ABL & 16)) {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
+                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
+                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
+                    }
                     // results of a column block leave while the next one is being computed
                     if (ks == 7 && nb >= 1) store_nb(nb - 1);
+                    // the eight fragment loads of the next K-step go out FIRST (left alone the scheduler sinks them
+                    // to the end of the K-step and the next one starts by waiting a full L2 round trip for them)
+                    if (nb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                 }
@@ -212,8 +239,10 @@ __device__ unsigned long long wn_lc_stamp_buf[8][16];
 #define LC_STAMP(i) do {} while (0)
 #endif
 
-template <int HN, bool LAST = false>
-__global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
+// W2: ONE workgroup of 512 threads per CU instead of two of 256: its two halves walk tiles independently (like two
+// workgroups) but share one weight image -- half the staging traffic, half the workgroups to dispatch.
+template <int HN, bool LAST = false, bool W2 = false>
+__global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_layer_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
     const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
@@ -224,7 +253,8 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
 #endif
     int stamp_i = 3;
     (void)stamp_i;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NT = W2 ? 512 : 256;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int n = lane & 15, q = lane >> 4;
     const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
     const wn_u4* PRl = Pl + 6 * 4 * 2 * 64;
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
                 for (int mb = 0; mb < 4; ++mb) ch[mb][e] = buf_ldf4(s.rh, s.vc + (e * 4 + mb) * 1024, 0);
         }
     };
-    const TileWalk tw = tile_walk(ntiles);
+    const TileWalk tw = W2 ? tile_walk_parts(ntiles, 2, (int)(threadIdx.x >> 8)) : tile_walk(ntiles);
     const int tstep = tw.step, tend = tw.end;
     float inv_m = 0.f, inv_r = 0.f;
 
@@ -429,11 +459,11 @@ __global__ __launch_bounds__(256, HN == 1 ? 2 : 1) void iaf_layer_c_kernel(
     if (tile < tend) load_tile(tile, bA, cA, hA);
     LC_STAMP(1);
     // the weight image is staged AFTER the first tile's operand loads are in flight
-    stage_words<LC_A_WORDS>(wpack, ldsw);
-    stage_words<LC_TAIL_WORDS>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
+    stage_words<LC_A_WORDS, NT>(wpack, ldsw);
+    stage_words<LC_TAIL_WORDS, NT>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
     if (LAST) {
-        stage_words<HC_A_WORDS>(ha.wpack, ldsw + LC_LDS_WORDS);
-        stage_words<HC_TAIL_WORDS>(ha.wpack + IAF_PH_FLOATS, ldsw + LC_LDS_WORDS + HC_A_WORDS);
+        stage_words<HC_A_WORDS, NT>(ha.wpack, ldsw + LC_LDS_WORDS);
+        stage_words<HC_TAIL_WORDS, NT>(ha.wpack + IAF_PH_FLOATS, ldsw + LC_LDS_WORDS + HC_A_WORDS);
         bmean = ldsf[LC_LDS_WORDS + HC_A_WORDS + 192];
         bscale = ldsf[LC_LDS_WORDS + HC_A_WORDS + 193];
         inv_h = ldsf[LC_LDS_WORDS + HC_A_WORDS + 194];
@@ -880,6 +910,8 @@ int wn_iaf_c_set_attrs(wn_handle* h) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_c_kernel<1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (LC_LDS_WORDS + HC_LDS_WORDS) * 4));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_c_kernel<1, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (LC_LDS_WORDS + HC_LDS_WORDS) * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_WORDS * 4));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_pair_c_kernel<2, true>),
@@ -921,6 +953,11 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
 // workgroups per CU of the hoisted layer / head kernels (57 KB of LDS; the 128-column variant
 // needs the whole register file)
 static int lc_slots(int hn) { return hn == 1 ? 2 : 1; }
+// 64-column tiles: one 512-thread workgroup per CU (two halves, one weight image) instead of two of 256
+static bool lc_w2() {
+    static const bool on = getenv("WN_LC_W2") && atoi(getenv("WN_LC_W2")) != 0;   // measured slower (46.3 vs 49.2 M samples/s at one utterance): off
+    return on;
+}
 
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
                     int d, int B, int64_t T, int num_cu, hipStream_t st) {
@@ -928,6 +965,13 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int slots = lc_slots(hn) * num_cu;
     const int grid = ntiles < slots ? ntiles : slots;
+    if (hn == 1 && lc_w2()) {
+        const int g2 = std::min(num_cu, (ntiles + 1) / 2);
+        hipLaunchKernelGGL((iaf_layer_c_kernel<1, false, true>), dim3(g2), dim3(512), LC_LDS_WORDS * 4, st,
+                           reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout), C, c_bstride,
+                           reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, HeadArgs{});
+        return;
+    }
     auto kern = hn == 1 ? iaf_layer_c_kernel<1> : iaf_layer_c_kernel<2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
@@ -961,6 +1005,13 @@ void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int6
     const int tiles_per_row = (int)(T / 64), ntiles = B * tiles_per_row;
     const int grid = ntiles < 2 * num_cu ? ntiles : 2 * num_cu;
     HeadArgs ha{Ch, reinterpret_cast<const unsigned*>(wpack_head), x, Mt, St, XR, T, first};
+    if (lc_w2()) {
+        hipLaunchKernelGGL((iaf_layer_c_kernel<1, true, true>), dim3(std::min(num_cu, (ntiles + 1) / 2)), dim3(512),
+                           (LC_LDS_WORDS + HC_LDS_WORDS) * 4, st, reinterpret_cast<const unsigned*>(lin),
+                           static_cast<unsigned*>(nullptr), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
+                           tiles_per_row, ntiles, ha);
+        return;
+    }
     hipLaunchKernelGGL((iaf_layer_c_kernel<1, true>), dim3(grid), dim3(256), (LC_LDS_WORDS + HC_LDS_WORDS) * 4, st,
                        reinterpret_cast<const unsigned*>(lin), static_cast<unsigned*>(nullptr), C, c_bstride,
                        reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, ha);

@@ -29,18 +29,18 @@ __device__ inline void buf_st2(unsigned w0, unsigned w1, __amdgpu_buffer_rsrc_t 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wn_u2, (wn_u2){w0, w1}), r, voff, soff, 0);
 }
 
-template <int NWORDS>
+template <int NWORDS, int NT = 256>
 __device__ inline void stage_words(const unsigned* __restrict__ wpack, unsigned* lds) {
-    constexpr int NV = NWORDS / 4, NCHUNK = NV / 256, REM = NV - NCHUNK * 256;
+    constexpr int NV = NWORDS / 4, NCHUNK = NV / NT, REM = NV - NCHUNK * NT;
     const wn_u4* src = reinterpret_cast<const wn_u4*>(wpack) + threadIdx.x;
     wn_u4* dst = reinterpret_cast<wn_u4*>(lds) + threadIdx.x;
     wn_u4 tmp[NCHUNK + 1];
 #pragma unroll
-    for (int k = 0; k < NCHUNK; ++k) tmp[k] = src[k * 256];
-    if (REM && (int)threadIdx.x < REM) tmp[NCHUNK] = src[NCHUNK * 256];
+    for (int k = 0; k < NCHUNK; ++k) tmp[k] = src[k * NT];
+    if (REM && (int)threadIdx.x < REM) tmp[NCHUNK] = src[NCHUNK * NT];
 #pragma unroll
-    for (int k = 0; k < NCHUNK; ++k) dst[k * 256] = tmp[k];
-    if (REM && (int)threadIdx.x < REM) dst[NCHUNK * 256] = tmp[NCHUNK];
+    for (int k = 0; k < NCHUNK; ++k) dst[k * NT] = tmp[k];
+    if (REM && (int)threadIdx.x < REM) dst[NCHUNK * NT] = tmp[NCHUNK];
     __syncthreads();
 }
 
@@ -71,6 +71,17 @@ __device__ inline TileWalk tile_walk(int ntiles) {
     }
 #endif
     return {(int)blockIdx.x, ntiles, (int)gridDim.x};
+}
+// the same walk for a workgroup made of `parts` independent 256-thread parts (part p of workgroup w walks like
+// workgroup parts * w + p of a grid parts times as large)
+__device__ inline TileWalk tile_walk_parts(int ntiles, int parts, int part) {
+#ifndef WN_NO_XCD_TILES
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, per = (ntiles + 7) >> 3;
+        return {xcd * per + parts * (int)(blockIdx.x >> 3) + part, min(ntiles, (xcd + 1) * per), parts * (int)(gridDim.x >> 3)};
+    }
+#endif
+    return {parts * (int)blockIdx.x + part, ntiles, parts * (int)gridDim.x};
 }
 
 // operand words of one K-step: hi and lo plane, HN columns
