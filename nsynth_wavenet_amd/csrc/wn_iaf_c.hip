@@ -142,7 +142,7 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             auto store_nb = [&](int nb) {
                 // column blocks past the end of the row fall outside the descriptor and are dropped
                 const int cb = (CK_NC / 16) * j + nb;
-                if ((WN_CK_ABL & 1) && acc[0][nb][0] != 12345.678f) return;      // keeps the accumulators live
+                if ((WN_CK_ABL & 1) && acc[0][nb][0] + acc[1][nb][1] + acc[2][nb][2] + acc[3][nb][3] != 12345.678f) return;   // keeps every accumulator live
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for bsz in 1 8; do
-for a in 0 1 2 4 8 16 15 31; do
+for a in ${@:-0 1 2 4 8 16 15 31}; do
   cp $R/vlibs/lib_abl$a.so $R/nsynth_wavenet_amd/lib/libwnhip.so
   rm -rf /tmp/abl; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl -o abl -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu $bsz > /dev/null 2>&1
   python - <<PY
