@@ -241,7 +241,8 @@ __device__ unsigned long long wn_lc_stamp_buf[8][16];
 
 // W2: ONE workgroup of 512 threads per CU instead of two of 256: its two halves walk tiles independently (like two
 // workgroups) but share one weight image -- half the staging traffic, half the workgroups to dispatch.
-template <int HN, bool LAST = false, bool W2 = false>
+// DMA: the weight image arrives by LDS-DMA, requested ahead of the first tile (short launches: few tiles per workgroup).
+template <int HN, bool LAST = false, bool W2 = false, bool DMA = false>
 __global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_layer_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
     const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
@@ -456,11 +457,38 @@ __global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_
     KOp<HN> bA[6], bB[6];
     f4 cA[4][HN], cB[4][HN], hA[4][HN], hB[4][HN];
     int tile = tw.first;
+    if (DMA && !LAST && !W2) {
+        // The weight image goes to LDS by LDS-DMA and is requested BEFORE the first tile's operands: loads return in
+        // order, so behind the tile's loads the image would arrive a full fabric round trip late (3.3 us of a 13 us
+        // workgroup life); in front of them it comes out of L2 while the tile is still on its way.
+        auto dma = [&](const unsigned* src, unsigned* dst, int nchunks) {
+            for (int i = wave; i < nchunks; i += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(i * 64 + lane) * 4),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+        };
+        constexpr int TAIL_CH = LC_TAIL_WORDS / 256, TAIL_REM = LC_TAIL_WORDS / 4 - TAIL_CH * 64;   // 8 chunks + 33 lanes
+        dma(wpack, ldsw, LC_A_WORDS / 256);
+        dma(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS, TAIL_CH);
+        if (wave == 0 && lane < TAIL_REM)       // the last 33 16-byte words of the image
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(wpack + IAF_P_FLOATS + TAIL_CH * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(ldsw + LC_A_WORDS + TAIL_CH * 256), 16, 0, 0);
+        const bool has_tile = tile < tend;
+        if (has_tile) load_tile(tile, bA, cA, hA);
+        LC_STAMP(1);
+        // the 16 HN operand loads of the tile may stay in flight; everything older (the image) has landed.  A plain
+        // s_barrier: __syncthreads() carries a fence that makes the compiler wait for vmcnt(0) here.
+        if (has_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * HN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
     if (tile < tend) load_tile(tile, bA, cA, hA);
     LC_STAMP(1);
     // the weight image is staged AFTER the first tile's operand loads are in flight
     stage_words<LC_A_WORDS, NT>(wpack, ldsw);
     stage_words<LC_TAIL_WORDS, NT>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
+    }
     if (LAST) {
         stage_words<HC_A_WORDS, NT>(ha.wpack, ldsw + LC_LDS_WORDS);
         stage_words<HC_TAIL_WORDS, NT>(ha.wpack + IAF_PH_FLOATS, ldsw + LC_LDS_WORDS + HC_A_WORDS);
@@ -972,7 +1000,12 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
                            reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, HeadArgs{});
         return;
     }
-    auto kern = hn == 1 ? iaf_layer_c_kernel<1> : iaf_layer_c_kernel<2>;
+    // few tiles per workgroup (one utterance): the start-up is a third of the workgroup's life and the DMA-staged
+    // image takes 5 % off the launch; with many tiles (eight utterances) the register-staged form is 2 % faster
+    static const int dma_env = getenv("WN_LC_DMA") ? atoi(getenv("WN_LC_DMA")) : -1;
+    const bool dma = dma_env >= 0 ? dma_env != 0 : ntiles <= 4 * grid;
+    auto kern = hn == 1 ? (dma ? iaf_layer_c_kernel<1, false, false, true> : iaf_layer_c_kernel<1>)
+                        : (dma ? iaf_layer_c_kernel<2, false, false, true> : iaf_layer_c_kernel<2>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
                        tiles_per_row, ntiles, HeadArgs{});
