@@ -474,6 +474,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_
                 (const __attribute__((address_space(1))) void*)(wpack + IAF_P_FLOATS + TAIL_CH * 256 + lane * 4),
                 (__attribute__((address_space(3))) void*)(ldsw + LC_A_WORDS + TAIL_CH * 256), 16, 0, 0);
         const bool has_tile = tile < tend;
+        __builtin_amdgcn_sched_barrier(0);      // the vmcnt below counts on the image's loads being OLDER than the tile's
         if (has_tile) load_tile(tile, bA, cA, hA);
         LC_STAMP(1);
         // the 16 HN operand loads of the tile may stay in flight; everything older (the image) has landed.  A plain
