@@ -1,4 +1,4 @@
-"""dev: compare an execution form with the default on given (B, F) shapes (run on the GPU box)."""
+"""dev: repeated calls of one form with CHANGING inputs (same or different shapes) against the default."""
 import json, os, sys
 os.environ.setdefault('WN_UNVERIFIED_FORMS', '1')     # the hoisted-resident form is withheld
 import numpy as np, torch
@@ -13,10 +13,8 @@ a, b = Engine(d, precision='f16x3').load_weights(w), Engine(d, precision=form).l
 for arg in sys.argv[2:]:
     B, F = (int(v) for v in arg.split('x'))
     mel = torch.rand(B, F, 80, device='cuda')
-    ra = a.iaf_generate(mel, None, seed=1, want=('x', 'rand_input'))
+    ra = a.iaf_generate(mel, None, seed=int(torch.randint(1 << 30, (1,))), want=('x', 'rand_input'))
     rb = b.iaf_generate(mel, ra['rand_input'], want=('x',))
     diff = (ra['x'] - rb['x']).abs()
-    T = ra['x'].shape[1]
     bad = (diff > 2e-5 * max(1.0, float(ra['x'].abs().max()))).nonzero()
-    first = bad[0].tolist() if len(bad) else None
-    print('B=%d F=%d T=%d blocks/CU %.2f maxdiff %.3e first bad %s nbad %d' % (B, F, T, T / 16 / 256, float(diff.max()), first, len(bad)), flush=True)
+    print('B=%d F=%d T=%d maxdiff %.3e nbad %d first %s' % (B, F, ra['x'].shape[1], float(diff.max()), len(bad), bad[0].tolist() if len(bad) else None), flush=True)
