@@ -34,9 +34,12 @@
 //     loads in flight during the MFMAs (vmcnt(0) before them: still fails), the LDS bias reads between MFMA and
 //     VALU (biases preloaded: still fails), accumulating out of place (in-place chains: still fails);
 //   * without the 64 wait states below HALF of all blocks are wrong in some register allocations and none in
-//     others, so the compiler's own MFMA->VALU spacing for v_mfma_f32_16x16x32_f16 is not sufficient here, and
-//     whatever the true requirement is, it is not a fixed number of wait states when a sibling wave's MFMAs are
-//     queued in the same matrix pipe.
+//     others; with them the rate drops to the rare event above.  A micro-benchmark of the bare pattern (twelve waves
+//     leave a barrier, read fragments from LDS, run the four chains of three MFMAs from zero, read the results with
+//     VALU compares; idle waves issuing LDS-DMA; scripts/ubench/mfma_hazard.hip) shows NO wrong value in 200 000
+//     iterations at any occupancy with the compiler's own spacing -- so it is not simply "too few wait states after
+//     v_mfma_f32_16x16x32_f16"; something else this kernel has (the inline-asm mixed-precision VALU ops around the
+//     MFMAs, the sc1 stores and polls in flight, the LDS-DMA into the fragment buffer) is part of it.  Unexplained.
 // The default form (one launch per layer, wn_iaf_c.hip) never shows this: its waves are not barrier-aligned into
 // simultaneous MFMA bursts, and its determinism / cross-form checks have run clean over >10^4 fuzz cases.
 //
