@@ -136,6 +136,13 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+RAMP_STEPS = 64
+
+
+def ramp_steps(warmup):
+    return max(0, RAMP_STEPS - warmup)
+
+
 def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every):
     """W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
     def step(i):
@@ -147,6 +154,10 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every):
             dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
+    # clock / cache ramp: a 20-step run after 3 warm-up steps measures the GPU still ramping its clocks (1.551 vs
+    # 1.508 ms per step on the same box); RAMP_STEPS extra untimed steps come first and are reported in the line
+    for i in range(ramp_steps(warmup)):
+        step(100000 + i)
     for i in range(warmup):
         step(i)
     fence()
@@ -334,6 +345,7 @@ def main():
             'world_size_seen': dist.get_world_size() if world > 1 else 1,
             'steps': args.steps,
             'warmup': args.warmup,
+            'ramp_steps': ramp_steps(args.warmup),       # untimed steps before the warm-up steps (clock ramp)
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
