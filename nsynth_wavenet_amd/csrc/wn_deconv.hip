@@ -286,6 +286,13 @@ __device__ inline unsigned dpp_shr1(unsigned old, unsigned src) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false);   // row_shr:1
 }
 
+// Ablation switches (measurement only, results are WRONG when set; scripts/ablate_cond.sh): 1 no stores, 2 the activation
+// operands loaded for the first channel block only, 4 the weight fragments staged for the first chunk only, 16 one MFMA
+// per product instead of three
+#ifndef WN_DC_ABL
+#define WN_DC_ABL 0
+#endif
+
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
     const unsigned* __restrict__ x, int cin, int xs, const unsigned* __restrict__ wp,
@@ -366,12 +373,12 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
         for (int e = 0; e < DC_NT; ++e) { vh[e] = nh[e]; vl[e] = nl[e]; }
 #pragma unroll
         for (int k = 0; k < NH; ++k) { hh[k] = nhh[k]; hl[k] = nhl[k]; }
-        if (c + 1 < nb32) loadB(c + 1, nh, nl, nhh, nhl);
+        if (c + 1 < nb32 && !(WN_DC_ABL & 2)) loadB(c + 1, nh, nl, nhh, nhl);
 #pragma unroll
       for (int tg = 0; tg < ntg; ++tg) {
         const int chunk = c * ntg + tg;
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunk) stage_load(chunk + 1);
+        if (chunk + 1 < nchunk && !(WN_DC_ABL & 4)) stage_load(chunk + 1);
         const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
 #pragma unroll
         for (int kl = 0; kl < DH_KC; ++kl) {
@@ -396,16 +403,26 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
                 for (int e = 0; e < DC_NT; ++e) {
                     f4 cc = acc[mb][e];
                     cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
+                    if (!(WN_DC_ABL & 16)) {
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
+                    }
                     acc[mb][e] = cc;
                 }
             }
             }
         }
-        if (chunk + 1 < nchunk) stage_store(chunk + 1, buf ^ 1);
+        if (chunk + 1 < nchunk && !(WN_DC_ABL & 4)) stage_store(chunk + 1, buf ^ 1);
         __syncthreads();
       }
+    }
+    if (WN_DC_ABL & 1) {      // keeps every accumulator live without the stores
+        float t = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < DC_NT; ++e) t += acc[mb][e][0] + acc[mb][e][1] + acc[mb][e][2] + acc[mb][e][3];
+        if (t != 12345.678f) return;
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
