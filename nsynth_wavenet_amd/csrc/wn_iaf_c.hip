@@ -242,8 +242,10 @@ __device__ unsigned long long wn_lc_stamp_buf[8][16];
 // W2: ONE workgroup of 512 threads per CU instead of two of 256: its two halves walk tiles independently (like two
 // workgroups) but share one weight image -- half the staging traffic, half the workgroups to dispatch.
 // DMA: the weight image arrives by LDS-DMA, requested ahead of the first tile (short launches: few tiles per workgroup).
-template <int HN, bool LAST = false, bool W2 = false, bool DMA = false>
-__global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_layer_c_kernel(
+// NOPF (HN = 2): no register double buffer for the next tile's operands, which lets two workgroups of the 128-column
+// form share a CU (each fragment read from LDS then feeds two column blocks: half the LDS traffic of HN = 1).
+template <int HN, bool LAST = false, bool W2 = false, bool DMA = false, bool NOPF = false>
+__global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1) void iaf_layer_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ C, int64_t c_bstride,
     const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_
                     f4 (&chn)[4][HN]) {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * TILE;
-        if (tile + tstep < tend) load_tile(tile + tstep, bn, cn, chn);
+        if (!NOPF && tile + tstep < tend) load_tile(tile + tstep, bn, cn, chn);
         f4 acc[4][HN];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -500,6 +502,13 @@ __global__ __launch_bounds__(W2 ? 512 : 256, (HN == 1 && !W2) ? 2 : 1) void iaf_
     inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
     inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
     LC_STAMP(2);
+    if (NOPF) {
+        while (tile < tend) {
+            body(tile, bA, cA, hA, bA, cA, hA);
+            tile += tstep;
+            if (tile < tend) load_tile(tile, bA, cA, hA);
+        }
+    } else
     while (tile < tend) {
         body(tile, bA, cA, hA, bB, cB, hB);
         tile += tstep;
@@ -999,6 +1008,18 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
         hipLaunchKernelGGL((iaf_layer_c_kernel<1, false, true>), dim3(g2), dim3(512), LC_LDS_WORDS * 4, st,
                            reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout), C, c_bstride,
                            reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, HeadArgs{});
+        return;
+    }
+    // many tiles per workgroup (several utterances): 128-column tiles WITHOUT the register double buffer, two workgroups
+    // per CU -- every fragment read from LDS feeds two column blocks (0.61 against 0.593 of the HBM peak at eight
+    // utterances); with few tiles it loses (0.35 against 0.435 at one utterance: the second tile's loads are exposed)
+    static const int nopf_env = getenv("WN_LC_NOPF") ? atoi(getenv("WN_LC_NOPF")) : -1;
+    const bool nopf = nopf_env >= 0 ? nopf_env != 0 : (int64_t)B * (T / 128) >= 8 * (int64_t)num_cu;
+    if (nopf && T % 128 == 0 && !getenv("WN_HN")) {
+        const int tpr = (int)(T / 128), nt2 = B * tpr, g2 = std::min(nt2, 2 * num_cu);
+        hipLaunchKernelGGL((iaf_layer_c_kernel<2, false, false, true, true>), dim3(g2), dim3(256), LC_LDS_WORDS * 4, st,
+                           reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout), C, c_bstride,
+                           reinterpret_cast<const unsigned*>(wpack), RS, d, tpr, nt2, HeadArgs{});
         return;
     }
     // few tiles per workgroup (one utterance): the start-up is a third of the workgroup's life and the DMA-staged
