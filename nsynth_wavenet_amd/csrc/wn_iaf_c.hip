@@ -43,6 +43,10 @@
 #ifndef WN_CK_ABL
 #define WN_CK_ABL 0
 #endif
+// Ablation of the layer kernel (measurement only, WRONG results): 1 gate without exp / rcp, 2 one MFMA per product in the K loop
+#ifndef WN_LC_ABL
+#define WN_LC_ABL 0
+#endif
 #ifndef WN_ENC_STAGE_AUX
 #define WN_ENC_STAGE_AUX 0
 #endif
@@ -349,7 +353,11 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
             for (int e = 0; e < HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
+#if WN_LC_ABL & 2
+                    acc[mb][e] = mfma_h(a[ks & 1][mb][0], bc[ks].h[e], acc[mb][e]);
+#else
                     acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         LC_STAMP(stamp_i);
@@ -372,8 +380,12 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
             for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
+#if WN_LC_ABL & 1
+                    g[mg][r] = fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r]) * fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]);
+#else
                     g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
                                tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
+#endif
             wn_u4 gh, gl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
