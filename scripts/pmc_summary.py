@@ -21,8 +21,9 @@ def key_of(name):
     base, targs = m.group(1), m.group(2) or ''
     if base == 'iaf_layer_h_kernel' and 'true' in targs:
         return base + '<first>'
-    if base == 'iaf_layer_c_kernel' and 'true' in targs:
-        return base + '<head>'
+    if base == 'iaf_layer_c_kernel':      # template <HN, LAST, W2, DMA, NOPF>: only LAST changes the work per launch
+        a = [x.strip() for x in targs.strip('<>').split(',')]
+        return base + '<head>' if len(a) > 1 and a[1] == 'true' else base
     if base == 'iaf_pair_c_kernel':
         return base + targs.replace(' ', '')
     if base in ('deconv_mfma_h_kernel', 'deconv_mfma_hs_kernel'):
