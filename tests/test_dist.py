@@ -93,3 +93,22 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub'], env=env2,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert bad.returncode != 0
+
+
+def test_bench_traffic_figure_follows_the_source_hash(monkeypatch):
+    """roofline.traffic is the committed PMC figure of the dominant kernel ONLY for the kernel sources it was measured
+    on: with the tree's hash it is the layer kernel's own entry (not the head variant's, whatever template flags the
+    kernel name carries), with any other hash it is None."""
+    import json
+    import bench
+    from nsynth_wavenet_amd import build
+    path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), 'profiles', 'r02_pmc_summary_f16x3.json')
+    d = json.load(open(path))
+    assert 'iaf_layer_c_kernel' in d['kernels'] and 'iaf_layer_c_kernel<head>' in d['kernels']
+    plain, head = d['kernels']['iaf_layer_c_kernel'], d['kernels']['iaf_layer_c_kernel<head>']
+    assert 0.9 * 58982400 <= plain['hbm_bytes_per_launch'] <= 1.3 * 58982400      # 768 B/sample: no wasted re-reads
+    assert head['hbm_bytes_per_launch'] != plain['hbm_bytes_per_launch']
+    monkeypatch.setattr(build, 'source_hash', lambda: d['source_hash'])
+    assert bench.pmc_traffic(1, 384, 'f16x3', True) == plain['hbm_bytes_per_launch']
+    monkeypatch.setattr(build, 'source_hash', lambda: 'not-the-measured-sources')
+    assert bench.pmc_traffic(1, 384, 'f16x3', True) is None
