@@ -44,6 +44,8 @@ PATH_BYTES_PER_SAMPLE = 98484
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+PROFILE_ROUND = 'r03'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
+DOMINANT_KERNEL = 'iaf_layer_c_kernel'
 
 
 def pmc_traffic(B, F, precision='f16x3', hoisted=False):
@@ -55,10 +57,12 @@ def pmc_traffic(B, F, precision='f16x3', hoisted=False):
     on; a summary without a hash, or with another one, is stale and gives None."""
     if precision == 'f32':
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
-    elif hoisted:
-        names, kernel = ['r02_pmc_summary_f16x3.json', 'r02_pmc_summary_f16x3_batch8.json'], 'iaf_layer_c_kernel'
+    elif precision in ('f16x3', 'f16x3-hoisted') and hoisted:
+        names, kernel = [PROFILE_ROUND + '_pmc_summary_f16x3.json', PROFILE_ROUND + '_pmc_summary_f16x3_batch8.json'], DOMINANT_KERNEL
+    elif precision in ('f16x3', 'f16x3-fused') and not hoisted:
+        names, kernel = [PROFILE_ROUND + '_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
     else:
-        names, kernel = ['r02_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
+        return None                      # no PMC summary of its own: never borrow another kernel's figure
     have = wbuild.source_hash()
     for name in names:
         try:
@@ -136,15 +140,22 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-RAMP_STEPS = 64
+def gpu_clocks(index):
+    """Shader / memory clock of GPU `index` as rocm-smi reports them right now (MHz strings), or None.  Recorded
+    before and after the timed region instead of lengthening the warm-up the command asked for."""
+    try:
+        out = subprocess.run(['rocm-smi', '-d', str(index), '--showclocks', '--json'], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, timeout=20).stdout.decode(errors='replace')
+        d = json.loads(out[out.index('{'):])
+        card = next(iter(d.values()))
+        pick = lambda key: next((str(v) for k, v in card.items() if key in k.lower()), None)   # noqa: E731
+        return {'sclk': pick('sclk'), 'mclk': pick('mclk')}
+    except Exception:                    # measurement garnish only: never fail the bench over it
+        return None
 
 
-def ramp_steps(warmup):
-    return max(0, RAMP_STEPS - warmup)
-
-
-def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every):
-    """W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
+def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp=0):
+    """`ramp` + W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
     def step(i):
         return eng.iaf_generate(mel, None, seed=1000 * rank + i, want=('wav',))['wav']
 
@@ -154,9 +165,9 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every):
             dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
-    # clock / cache ramp: a 20-step run after 3 warm-up steps measures the GPU still ramping its clocks (1.551 vs
-    # 1.508 ms per step on the same box); RAMP_STEPS extra untimed steps come first and are reported in the line
-    for i in range(ramp_steps(warmup)):
+    # --ramp-steps N (default 0): extra untimed steps before the W the command asked for -- a 20-step run after 3
+    # warm-up steps catches the GPU still ramping its clocks (1.551 vs 1.508 ms per step on one box); off unless asked
+    for i in range(ramp):
         step(100000 + i)
     for i in range(warmup):
         step(i)
@@ -198,36 +209,6 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
                 'frac': achieved_gbps / PEAK_HBM_GBPS,
                 'note': '768 B/sample/layer in this kernel + 256 B/sample/layer written by iaf_cond_h_kernel '
                         '(vs 1536 B/sample/layer of the fused layer kernel)'}
-    elif eng.precision in ('f16x3-resident', 'f16x3-hoisted-resident'):
-        # one launch = every layer of ONE flow over one pass; the event pairs bracket all such launches of a call:
-        # the layer-granular bytes of the whole residual stack over their summed time
-        nl = sum(eng.hp.num_iaf_layers)
-        per = LAYER_BYTES_PER_SAMPLE if eng.precision == 'f16x3-resident' else LAYER_BYTES_PER_SAMPLE_HOISTED
-        tot_b, tot_f = per * nl * B * T, LAYER_FLOP_PER_SAMPLE * nl * B * T
-        # launches of one call: flows x utterances x passes (a pass = 256 CUs x 128 or 192 resident columns)
-        per_call = len(eng.hp.num_iaf_layers) * B * -(-T // (256 * (128 if eng.precision == 'f16x3-resident' else 192)))
-        bytes_per_launch = tot_b / per_call
-        flops_per_launch = tot_f / per_call
-        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
-        achieved_tf = flops_per_launch / avg_layer_s / 1e12
-        kern = 'iaf_srf_kernel (all layers of a flow per launch, enc in registers, l in LDS)' if eng.precision == 'f16x3-resident' \
-            else 'iaf_res_kernel (all layers of a flow per launch on hoisted conditioning, l in LDS)'
-        roof = {'kernel': kern + ', split-fp16 MFMA; EXPERIMENTAL form', 'bound': 'hbm', 'achieved': achieved_gbps,
-                'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': achieved_gbps / PEAK_HBM_GBPS,
-                'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS}}
-    elif eng.precision == 'f16x3-pipe':
-        # ONE launch = every layer and head of the student; the fused form's bytes (1536 B per
-        # sample and layer + 1296 B per head) over the launch time
-        nl = sum(eng.hp.num_iaf_layers)
-        nh = len(eng.hp.num_iaf_layers)
-        bytes_per_launch = (LAYER_BYTES_PER_SAMPLE * nl + 1296 * nh) * B * T
-        flops_per_launch = (LAYER_FLOP_PER_SAMPLE * nl + 41600 * nh) * B * T
-        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
-        achieved_tf = flops_per_launch / avg_layer_s / 1e12
-        roof = {'kernel': 'iaf_pipe_kernel (all residual layers and heads, one persistent launch, split-fp16 MFMA)',
-                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                'frac': achieved_gbps / PEAK_HBM_GBPS,
-                'mfma_view': {'executed_fp16_TFLOPs': 3 * achieved_tf, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS}}
     elif eng.precision.startswith('f16x3'):
         # split-fp16 operands on the fp16 MFMA: 3 MFMAs per product -> the matrix pipe needs
         # 3*61440 fp16-FLOP/sample at a 2.5 PFLOP/s peak (0.07 ns) vs 1536 B/sample at 8 TB/s
@@ -296,8 +277,10 @@ def main():
                     help='skip the second roofline block (8 utterances per GPU) and the PCIe-inclusive timing')
     ap.add_argument('--layer-events-every', type=int, default=4,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
-    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f16x3-hoisted-resident', 'f32'],
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
+    ap.add_argument('--ramp-steps', type=int, default=0,
+                    help='extra untimed steps before the --warmup steps (clock ramp); 0 = exactly the protocol asked for')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -327,31 +310,42 @@ def main():
     T = eng.iaf_length(F)
     mel_host = np.random.RandomState(12345 + rank).uniform(0, 1, [B, F, 80]).astype(np.float32)
     mel = torch.from_numpy(mel_host).to(dev)
+    clocks_before = gpu_clocks(local) if rank == 0 else None
     elapsed, layer_ms, layer_launches, wav = measure(eng, mel, args.steps, args.warmup, rank, world, local, dev,
-                                                     args.layer_events_every)
+                                                     args.layer_events_every, ramp=args.ramp_steps)
+    clocks_after = gpu_clocks(local) if rank == 0 else None
     assert wav.shape == (B, T) and bool(torch.isfinite(wav).all())
+    eng.check_range()                     # raises if a split-fp16 operand left the fp16 range during the timed calls
+    seen = world
+    if world > 1:                         # the world size the collective actually spans, not the environment's word
+        ws = torch.ones(1, device=dev)
+        dist.all_reduce(ws)
+        seen = int(ws.item())
 
+    rec = None
     if rank == 0:
         total_samples = world * B * T * args.steps
         value = total_samples / elapsed
         roof = roofline_of(eng, B, F, T, layer_ms, layer_launches)
         dtype = 'f32' if eng.precision == 'f32' else \
-            'f32 storage; contractions as split-fp16 (hi+lo, 3 fp16 MFMAs per product) with fp32 accumulate'
+            'split-fp16: activations stored as fp16 hi+lo pairs (32 bits per value, 22-bit significand, fp16 exponent ' \
+            'range), contractions as 3 fp16 MFMAs per product with fp32 accumulate; conditioning term and outputs fp32'
         rec = {
             'metric': '16 kHz audio samples/sec, parallel-WaveNet (IAF student) generation',
             'value': value,
             'unit': 'samples/s',
             'n_gpus': world,
-            'world_size_seen': dist.get_world_size() if world > 1 else 1,
+            'world_size_seen': seen,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ramp_steps': ramp_steps(args.warmup),       # untimed steps before the warm-up steps (clock ramp)
+            'ramp_steps': args.ramp_steps,       # extra untimed steps before the warm-up steps (0 unless --ramp-steps)
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': dtype,
             'data': 'synthetic',
+            'clocks': {'before': clocks_before, 'after': clocks_after, 'source': 'rocm-smi --showclocks, GPU of rank 0'},
             'config': {
                 'workload': 'BASELINE.json configs[1]: parallel_wavenet.json IAF student generation, '
                             'synthetic 80-dim mel, 16 kHz, {} utterance(s) of {} frames = {} samples per GPU per step'
@@ -391,6 +385,31 @@ def main():
             r8.update({'batch_per_gpu': 8, 'steps': n8, 'ms_per_step': el8 / n8 * 1e3,
                        'samples_per_sec': 8 * T * n8 / el8})
             rec['roofline_b8'] = r8
+    if world > 1 and not args.no_extras:
+        # The per-GPU shares of BASELINE configs[2] (64 utterances over 8 GPUs = 8 per GPU, this model) and configs[4]
+        # (parallel_wavenet_gauss.json as shipped, 128 over 8 = 16 per GPU): timed on every rank, MAX over ranks,
+        # aggregate = all ranks' samples over that time.  Weak scaling like the headline figure.
+        def share(engine, nb, seed, steps):
+            melb = torch.from_numpy(np.random.RandomState(seed + rank).uniform(0, 1, [nb, F, 80]).astype(np.float32)).to(dev)
+            el, _, _, w = measure(engine, melb, steps, 2, rank, world, local, dev, 1 << 30)
+            assert w.shape == (nb, T) and bool(torch.isfinite(w).all())
+            return {'batch_per_gpu': nb, 'utterances': nb * world, 'steps': steps, 'ms_per_step': el / steps * 1e3,
+                    'samples_per_sec': world * nb * T * steps / el, 'x_realtime': world * nb * T * steps / el / 16000.0}
+        n_s = max(3, min(args.steps, 10))
+        c2 = share(eng, 8, 777, n_s)
+        with open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet_gauss.json')) as f:
+            hp4 = cfg.load_hparams(json.load(f))
+        w4 = wts.synthetic_weights(hp4, 'student', seed=1234, init='tf') if rank == 0 else None
+        w4 = wdist.broadcast_weights(w4, hp4, 'student', src=0, device=dev)
+        eng4 = Engine(hp4, kind='student', device=dev, precision=args.precision).load_weights(w4)
+        c4 = share(eng4, 16, 888, n_s)
+        eng4.close()
+        if rank == 0:
+            c2['workload'] = 'BASELINE.json configs[2] share: parallel_wavenet.json, 8 utterances of {} frames per GPU'.format(F)
+            c4['workload'] = 'BASELINE.json configs[4] share: parallel_wavenet_gauss.json as shipped (private deconv ' \
+                             'stacks), 16 utterances of {} frames per GPU'.format(F)
+            rec['config2_share'] = c2
+            rec['config4_share'] = c4
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(hp_dict, F)

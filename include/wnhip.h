@@ -31,8 +31,13 @@
  *     workspace too small, WN_EIO HIP runtime error, WN_ESTATE wrong call
  *     order).  Nothing throws or aborts across the ABI; the message is
  *     available from wn_last_error().
- *   - A handle is immutable after wn_finalize() and may be shared by
- *     concurrent callers that use distinct workspaces and streams.
+ *   - Concurrency.  After wn_finalize() the weights and every table of a handle are read-only, and the
+ *     student calls (wn_deconv, wn_iaf_generate*, wn_iaf_range_status, wn_clip_quant) keep all per-call
+ *     state -- including the range-guard word -- in the caller's workspace: concurrent callers may share
+ *     one student handle when each uses its own workspace and stream.  NOT shareable: the error string
+ *     behind wn_last_error (last writer wins), the measurement aid wn_profile_* (event list on the
+ *     handle), and the autoregressive calls of a teacher handle (wn_ar_generate caches its hipGraph on
+ *     the handle, wn_ar_set_graph changes handle state): use one teacher handle per concurrent caller.
  */
 #ifndef WNHIP_H_
 #define WNHIP_H_
@@ -52,6 +57,13 @@ extern "C" {
 #define WN_ENOMEM  (-12)
 #define WN_EIO     (-5)
 #define WN_ESTATE  (-1)
+#define WN_ERANGE  (-34)   /* wn_iaf_range_status: an activation left the fp16 range of the split-fp16 arithmetic */
+
+/* `form` of wn_iaf_generate_form / wn_iaf_workspace_bytes_form: which arithmetic ONE call runs in */
+#define WN_FORM_DEFAULT     (-1)  /* what the handle was created for (wn_config.precision / cond_mode) */
+#define WN_FORM_F16X3        0    /* split-fp16 MFMA, conditioning placed by the handle's cond_mode policy */
+#define WN_FORM_F32          1    /* fp32 MFMA: no fp16 range limit, ~2.4x slower */
+#define WN_FORM_F16X3_FUSED  2    /* split-fp16 MFMA without the hoisted-conditioning workspace */
 
 #define WN_MAX_DECONV 4
 #define WN_MAX_FLOWS  8
@@ -99,8 +111,9 @@ typedef struct wn_config {
     int32_t cond_mode;                      /* where the split-fp16 path evaluates the per-layer
                                                conditioning 1x1s: 0 default (= 2 unless the
                                                environment says WN_COND=fused or the projected term
-                                               of the call would exceed 96 GB), 1 inside every layer
-                                               kernel, 2 one GEMM per deconv stack */
+                                               of the call would exceed a third of the device memory
+                                               / half of what was free at wn_create), 1 inside every
+                                               layer kernel, 2 one GEMM per deconv stack */
     int32_t use_resize_conv;                /* upsampler = nearest-neighbour resize + SAME conv
                                                (masked.py:294-322) instead of transposed conv;
                                                variables <prefix>resize_conv_i/{W,biases} */
@@ -164,6 +177,26 @@ int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F,
                     float* mean_tot, float* scale_tot, float* rand_out,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* The same call in an explicitly named arithmetic (every student handle carries the weights in both packings), and
+ * its workspace size.  wn_iaf_generate(h, ...) == wn_iaf_generate_form(h, WN_FORM_DEFAULT, ...); wn_workspace_bytes
+ * (default form) also covers WN_FORM_F32 and WN_FORM_F16X3_FUSED, so a re-run never needs a larger workspace.
+ *
+ * fp16 range guard.  The split-fp16 forms carry activations as fp16 hi+lo pairs: 22-bit significand, but the fp16
+ * EXPONENT range -- |value| >= 65504 would become inf where the reference's fp32 graph is still finite (scale may reach
+ * e^7 per flow, parallel_wavenet.py:105-114).  Every kernel that produces such pairs (upsampler, start conv, residual
+ * layers) checks the magnitudes it converts and raises a status word at the head of the call's workspace; the call then
+ * writes NaN to every float output (idx = 0) instead of audio computed from saturated operands.  The generate call
+ * itself stays asynchronous; wn_iaf_range_status(h, ws, stream) SYNCHRONISES the stream, reads that word and returns
+ * WN_OK or WN_ERANGE -- on WN_ERANGE re-run the call with wn_iaf_generate_form(h, WN_FORM_F32, ...) (same workspace).
+ * The Python Engine does exactly that by itself (Engine.iaf_generate(check_range=True), the default).  Never silent. */
+int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, int B, int F,
+                         const float* noise, uint64_t seed,
+                         float* wav, int32_t* idx, float* x_raw,
+                         float* mean_tot, float* scale_tot, float* rand_out,
+                         void* ws, size_t ws_bytes, void* stream);
+size_t wn_iaf_workspace_bytes_form(const wn_handle* h, int form, int B, int F);
+int wn_iaf_range_status(wn_handle* h, const void* ws, void* stream);
+
 /* _clip_quant_scale on its own (parallel_wavenet.py:347-359 with
  * utils.cast_quantize / inv_cast_quantize / inv_mu_law, utils.py:108-159):
  * x[n] -> wav[n], idx[n].  Bit-exact integer index. */
@@ -224,7 +257,11 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
 /* wn_ar_generate replays the step from a hipGraph (16 steps per graph) when the caller's stream can be
  * captured (any stream but the legacy null stream); enable = 0 makes it issue plain launches instead
  * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  A failed capture falls back to
- * plain launches by itself and never leaves the caller's stream in capture mode. */
+ * plain launches by itself and never leaves the caller's stream in capture mode.
+ * Environment WN_AR_PERSIST=1 (opt-in, measured slower than the launches: DESIGN.md 3.4) selects the persistent
+ * single-launch step for batches below 4; in that mode wn_ar_generate BLOCKS (it ends in a stream synchronise and
+ * reads an error word back) and returns WN_EIO when a hand-off timed out.  A configuration the persistent kernel
+ * cannot hold (width + skip + gate > 5 * min(CUs, width), e.g. wavenet_ce.json) silently keeps the per-layer launches. */
 int wn_ar_set_graph(wn_handle* h, int enable);
 
 /* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher

@@ -53,7 +53,10 @@ def inv_mu_law_numpy(x, mu=255.0):
 
 
 def cast_quantize_numpy(x, quant_chann):
-    return np.floor(np.asarray(x) * quant_chann / 2).astype(np.int32)
+    """auxilaries/utils.py:162-164 of the reference: scale, then astype(int32) -- numpy TRUNCATES toward zero here
+    (the TF twin cast_quantize floors, utils.py:153-154; the two differ for negative non-grid inputs, and the
+    reference only ever feeds this helper values that already lie on the grid)."""
+    return (np.asarray(x) * quant_chann / 2).astype(np.int32)
 
 
 def inv_cast_quantize_numpy(x_quantized, quant_chann):

@@ -84,8 +84,9 @@ def run(args, synth_fn):
     rank, world, local = wdist.env_rank_world()
     if world > 1:
         import torch
-        wdist.init_process_group()
-        torch.cuda.set_device(local)
+        wdist.init_process_group()           # nccl (= RCCL) with a GPU, gloo without (host-only tests)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
     else:
         os.environ.setdefault('HIP_VISIBLE_DEVICES', str(args.gpu_id))
     logging.basicConfig(level=getattr(logging, str(args.log).upper().replace('WARN', 'WARNING').replace(

@@ -57,7 +57,7 @@ def iaf_length(hparams, num_frames):
 
 
 # name -> (wn_config.precision, wn_config.cond_mode)
-PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f16x3-pipe': (0, 3), 'f16x3-resident': (0, 4), 'f16x3-hoisted-resident': (0, 5), 'f32': (1, 0)}
+PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}
 
 
 def default_precision():

@@ -70,6 +70,22 @@ __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned&
     lo = l;
 }
 
+// Range guard of the split representation: hi = f16(x) is +-inf from |x| >= 65520 on (and the lo half NaN), where the
+// reference's fp32 graph is still finite.  Every kernel that PRODUCES split words keeps the running maximum of the
+// magnitudes it splits (one v_max3_f32 per pair) and raises bit 0 of the call's status word when that reaches the
+// largest finite half; wn_iaf_generate then NaN-poisons its outputs and wn_iaf_range_status reports WN_ERANGE, so the
+// caller re-runs on the fp32-MFMA form (the Python Engine does that by itself).  NaNs do not raise the maximum: one
+// can only come out of an earlier inf, which was flagged where it was produced.
+constexpr float WN_HALF_MAX = 65504.f;
+__device__ inline void wn_range_track(float& amax, float x0, float x1) { amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1))); }
+__device__ inline void wn_range_flag(float amax, unsigned* status) {
+    if (status && !(amax < WN_HALF_MAX)) atomicOr(status, 1u);
+}
+__device__ inline void wn_split_pair_t(float x0, float x1, unsigned& hi, unsigned& lo, float& amax) {
+    wn_range_track(amax, x0, x1);
+    wn_split_pair(x0, x1, hi, lo);
+}
+
 __device__ inline void wn_join_pair(unsigned hi, unsigned lo, float& x0, float& x1) {
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(hi), "v"(lo));
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(hi), "v"(lo));

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_kernel(
 
 // mel [B,F,C] -> split-fp16 pair planes [B][2][C/2][xs] (zero padded)
 __global__ void mel_to_split_kernel(const float* __restrict__ mel, unsigned* __restrict__ out,
-                                    int F, int C, int xs) {
+                                    int F, int C, int xs, unsigned* __restrict__ status) {
     const int b = blockIdx.z, cp = blockIdx.y;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= xs) return;
@@ -150,7 +150,9 @@ __global__ void mel_to_split_kernel(const float* __restrict__ mel, unsigned* __r
     unsigned hw = 0, lw = 0;
     if (f >= 0 && f < F) {
         const float* m = mel + ((size_t)b * F + f) * C + 2 * cp;
-        wn_split_pair(m[0], m[1], hw, lw);
+        float amax = 0.f;
+        wn_split_pair_t(m[0], m[1], hw, lw, amax);
+        wn_range_flag(amax, status);
     }
     out[((size_t)b * C + cp) * xs + col] = hw;
     out[((size_t)b * C + C / 2 + cp) * xs + col] = lw;
@@ -286,13 +288,6 @@ __device__ inline unsigned dpp_shr1(unsigned old, unsigned src) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false);   // row_shr:1
 }
 
-// Ablation switches (measurement only, results are WRONG when set; scripts/ablate_cond.sh): 1 no stores, 2 the activation
-// operands loaded for the first channel block only, 4 the weight fragments staged for the first chunk only, 16 one MFMA
-// per product instead of three
-#ifndef WN_DC_ABL
-#define WN_DC_ABL 0
-#endif
-
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
     const unsigned* __restrict__ x, int cin, int xs, const unsigned* __restrict__ wp,
@@ -373,12 +368,12 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
         for (int e = 0; e < DC_NT; ++e) { vh[e] = nh[e]; vl[e] = nl[e]; }
 #pragma unroll
         for (int k = 0; k < NH; ++k) { hh[k] = nhh[k]; hl[k] = nhl[k]; }
-        if (c + 1 < nb32 && !(WN_DC_ABL & 2)) loadB(c + 1, nh, nl, nhh, nhl);
+        if (c + 1 < nb32) loadB(c + 1, nh, nl, nhh, nhl);
 #pragma unroll
       for (int tg = 0; tg < ntg; ++tg) {
         const int chunk = c * ntg + tg;
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunk && !(WN_DC_ABL & 4)) stage_load(chunk + 1);
+        if (chunk + 1 < nchunk) stage_load(chunk + 1);
         const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds[buf]) + lane;
 #pragma unroll
         for (int kl = 0; kl < DH_KC; ++kl) {
@@ -403,26 +398,16 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
                 for (int e = 0; e < DC_NT; ++e) {
                     f4 cc = acc[mb][e];
                     cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
-                    if (!(WN_DC_ABL & 16)) {
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
-                    }
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, vl[e]), cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, vh[e]), cc, 0, 0, 0);
                     acc[mb][e] = cc;
                 }
             }
             }
         }
-        if (chunk + 1 < nchunk && !(WN_DC_ABL & 4)) stage_store(chunk + 1, buf ^ 1);
+        if (chunk + 1 < nchunk) stage_store(chunk + 1, buf ^ 1);
         __syncthreads();
       }
-    }
-    if (WN_DC_ABL & 1) {      // keeps every accumulator live without the stores
-        float t = 0.f;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int e = 0; e < DC_NT; ++e) t += acc[mb][e][0] + acc[mb][e][1] + acc[mb][e][2] + acc[mb][e][3];
-        if (t != 12345.678f) return;
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -460,7 +445,7 @@ __global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict_
 // one channel PAIR x 64 q columns; hi words to row cp, lo words to row cout/2 + cp.
 __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
     const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
-    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act) {
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act, unsigned* __restrict__ status) {
     __shared__ float tile[2][DI_MAXS][DC_QT + 1];
     const int cp = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * DC_QT;
@@ -475,16 +460,18 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
     unsigned* yh = y + ((size_t)b * cout + cp) * ys + yoff;
     unsigned* yl = yh + (size_t)(cout / 2) * ys;
     const int64_t n0 = (int64_t)S * q0 - pL;
+    float amax = 0.f;
     for (int i = threadIdx.x; i < S * DC_QT; i += 256) {
         const int q = i / S, r = i - q * S;
         const int64_t nn = n0 + i;
         if (nn >= 0 && nn < SL) {
             unsigned hw, lw;
-            wn_split_pair(apply_act(tile[0][r][q] + b0, act), apply_act(tile[1][r][q] + b1, act), hw, lw);
+            wn_split_pair_t(apply_act(tile[0][r][q] + b0, act), apply_act(tile[1][r][q] + b1, act), hw, lw, amax);
             yh[nn] = hw;
             yl[nn] = lw;
         }
     }
+    wn_range_flag(amax, status);
 }
 
 // Last layer of the split-fp16 path: weave the phases AND emit the G4 layout of wn_iaf_h.hip
@@ -493,7 +480,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
 constexpr int DG_Q = 32;
 __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
-    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act) {
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act, unsigned* __restrict__ status) {
     __shared__ float tile[8][DI_MAXS][DG_Q + 1];
     const int g = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * DG_Q;
@@ -517,6 +504,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     wn_u4* yh = reinterpret_cast<wn_u4*>(y + ((size_t)b * cout * ys)) + (size_t)g * ys + yoff;
     wn_u4* yl = yh + (size_t)ng * ys;
     const int64_t n0 = (int64_t)S * q0 - pL;
+    float amax = 0.f;
     for (int i = threadIdx.x; i < S * DG_Q; i += 256) {
         const int q = i / S, r = i - q * S;
         const int64_t nn = n0 + i;
@@ -525,8 +513,8 @@ __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
 #pragma unroll
             for (int slot = 0; slot < 4; ++slot) {
                 unsigned a, c2;
-                wn_split_pair(apply_act(tile[2 * slot][r][q] + bs[2 * slot], act),
-                              apply_act(tile[2 * slot + 1][r][q] + bs[2 * slot + 1], act), a, c2);
+                wn_split_pair_t(apply_act(tile[2 * slot][r][q] + bs[2 * slot], act),
+                                apply_act(tile[2 * slot + 1][r][q] + bs[2 * slot + 1], act), a, c2, amax);
                 hw[slot] = a;
                 lw[slot] = c2;
             }
@@ -534,6 +522,7 @@ __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
             yl[nn] = lw;
         }
     }
+    wn_range_flag(amax, status);
 }
 
 }  // namespace
@@ -657,18 +646,18 @@ size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F) {
 }
 
 int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* enc_cm,
-                  int64_t enc_stride, void* scratch, hipStream_t st, bool split_out) {
+                  int64_t enc_stride, void* scratch, hipStream_t st, bool split_out, unsigned* status, int prec) {
     const wn_config& c = h->cfg;
     const DeconvStackPack& sp = h->stacks[si];
-    // split-fp16 GEMMs when the handle runs in f16x3 mode and every layer's shape supports them
-    bool h_gemm = c.precision == WN_PREC_F16X3;
+    // split-fp16 GEMMs when the call runs in f16x3 mode and every layer's shape supports them
+    bool h_gemm = (prec < 0 ? c.precision : prec) == WN_PREC_F16X3;
     for (const DeconvLayerPack& lp : sp.layers) h_gemm = h_gemm && lp.w_off_h != 0;
     float* buf = reinterpret_cast<float*>(scratch);
     int xs = dc_row_stride(F);
     if (h_gemm) {
         dim3 g((xs + 255) / 256, c.n_mel / 2, B);
         hipLaunchKernelGGL(mel_to_split_kernel, g, dim3(256), 0, st, mel, reinterpret_cast<unsigned*>(buf), F,
-                           c.n_mel, xs);
+                           c.n_mel, xs, status);
     } else {
         dim3 g((xs + 255) / 256, c.n_mel, B);
         hipLaunchKernelGGL(mel_to_cm_kernel, g, dim3(256), 0, st, mel, buf, F, c.n_mel, xs);
@@ -728,12 +717,13 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         if ((last && split_out) || next_g4) {
             dim3 gi(Qp / DG_Q, lp.cout / 8, B);
             hipLaunchKernelGGL(deconv_interleave_g4_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
-                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act);
+                               reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act,
+                               status);
         } else if (!last && h_gemm) {
             dim3 gi(Qp / DC_QT, lp.cout / 2, B);
             hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
                                reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL,
-                               c.upsample_act);
+                               c.upsample_act, status);
         } else {
             dim3 gi(Qp / DC_QT, lp.cout, B);
             hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,

@@ -1,6 +1,7 @@
 // Handle lifecycle, variable table and weight upload of libwnhip.so.
 // Replaces graph construction + Saver.restore of the reference
 // (wavenet/parallelgen.py:11-41, wavenet/fastgen.py:61-88,118-147).
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 
@@ -100,11 +101,8 @@ static int validate(const wn_config& c) {
         return wn_fail(nullptr, WN_EINVAL, "config: bad upsample_act");
     if (c.precision != WN_PREC_F16X3 && c.precision != WN_PREC_F32)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown precision mode %d", c.precision);
-    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_RESHOIST)
-        return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d", c.cond_mode);
-    if (c.cond_mode == WN_COND_RESHOIST && !getenv("WN_UNVERIFIED_FORMS"))
-        return wn_fail(nullptr, WN_EINVAL, "config: conditioning mode 5 (hoisted-resident) is withheld: it is not parity-clean "
-                       "(wn_iaf_r.hip header); set WN_UNVERIFIED_FORMS=1 to run it for investigation");
+    if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_HOISTED)
+        return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d (0 default, 1 fused, 2 hoisted)", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
         if (c.num_stages < 7)
             return wn_fail(nullptr, WN_EINVAL, "config: the IAF kernels tile time in 64-sample blocks and need "
@@ -165,12 +163,17 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         h->num_cu = prop.multiProcessorCount;
         h->hoist_limit_bytes = (double)prop.totalGlobalMem / 3.0;   // 96 GB on a 288 GB MI355X
     }
+    {
+        // ... and never more than half of what is FREE right now: on a GPU another process already fills, the default
+        // placement becomes the fused form (no projected-term workspace) instead of an allocation failure later.
+        // Resolved ONCE here: wn_workspace_bytes and wn_iaf_generate must agree on the form.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+            h->hoist_limit_bytes = std::min(h->hoist_limit_bytes, (double)free_b * 0.5);
+    }
     if (const char* e = getenv("WN_COND")) {                         // read ONCE: sizing and generate calls must agree
         if (!strcmp(e, "fused")) h->cond_env_mode = WN_COND_FUSED;
         else if (!strcmp(e, "hoisted")) h->cond_env_mode = WN_COND_HOISTED;
-        else if (!strcmp(e, "pipe")) h->cond_env_mode = WN_COND_PIPE;
-        else if (!strcmp(e, "resident")) h->cond_env_mode = WN_COND_RESIDENT;
-        else if (!strcmp(e, "hoisted-resident") && getenv("WN_UNVERIFIED_FORMS")) h->cond_env_mode = WN_COND_RESHOIST;
     }
     h->frame_shift = 1;
     for (int j = 0; j < cfg->n_deconv; ++j) h->frame_shift *= cfg->deconv_stride[j];
@@ -292,6 +295,12 @@ extern "C" int64_t wn_ar_length(const wn_handle* h, int F) {
 extern "C" size_t wn_workspace_bytes(const wn_handle* h, int B, int F) {
     if (!h || !h->finalized || B < 1 || F < 1) return 0;
     return h->cfg.kind == WN_KIND_STUDENT ? wn_iaf_workspace_bytes(h, B, F) : wn_ar_workspace_bytes(h, B, F);
+}
+
+extern "C" size_t wn_iaf_workspace_bytes_form(const wn_handle* h, int form, int B, int F) {
+    if (!h || !h->finalized || h->cfg.kind != WN_KIND_STUDENT || B < 1 || F < 1) return 0;
+    if (form < WN_FORM_DEFAULT || form > WN_FORM_F16X3_FUSED) return 0;
+    return wn_iaf_workspace_bytes(h, B, F, form);
 }
 
 extern "C" const char* wn_last_error(const wn_handle* h) {

@@ -81,9 +81,10 @@ __global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __
 // zero the left pads of `rows` rows (row stride rs floats, pad floats each)
 // zero left pads of both activation buffers and of the flow input, one launch (blockIdx.z picks)
 __global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
-                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows) {
+                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status) {
     const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row == 0 && c == 0 && blockIdx.z == 0) *status = 0u;        // range-guard word of this call (wn_codec.h)
     if (blockIdx.z < 2) {
         float* p = blockIdx.z ? lB : lA;
         if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
@@ -389,14 +390,20 @@ __device__ inline void clip_quant_one(float y, int Q, int mu, float& wav, int& q
 __global__ void iaf_final_kernel(const float* __restrict__ x0, const float* __restrict__ Mt,
                                  const float* __restrict__ St, int64_t n, int Q, int mu,
                                  float* __restrict__ wav, int* __restrict__ idx, float* __restrict__ xraw,
-                                 float* __restrict__ mean_tot, float* __restrict__ scale_tot) {
+                                 float* __restrict__ mean_tot, float* __restrict__ scale_tot,
+                                 const unsigned* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float s = fminf(St[i], EXP_7);                    // :327
-    const float m = Mt[i];
-    const float y = x0[i] * s + m;                          // :330
+    // A split-fp16 operand left the fp16 range somewhere in this call (wn_codec.h): whatever the flows computed after
+    // that is not the reference's result.  Never hand it out as audio -- every float output becomes NaN, the index 0;
+    // wn_iaf_range_status() reports WN_ERANGE and the caller re-runs the call with wn_iaf_generate_prec(.., 1 = fp32).
+    const bool bad = *status != 0u;
+    float s = fminf(St[i], EXP_7);                          // :327
+    float m = Mt[i];
+    float y = x0[i] * s + m;                                // :330
     float w; int qi;
     clip_quant_one(y, Q, mu, w, qi);
+    if (bad) { w = y = m = s = __builtin_nanf(""); qi = 0; }
     wav[i] = w;
     if (idx) idx[i] = qi;
     if (xraw) xraw[i] = y;
@@ -417,15 +424,12 @@ __global__ void clip_quant_kernel(const float* __restrict__ x, int64_t n, int Q,
 struct IafLayout {
     int64_t T, TE, RS;
     int XR, c0;
-    size_t enc, lA, lB, x, x0, M, S, C, scratch, total;   // byte offsets
+    size_t status, enc, lA, lB, x, x0, M, S, C, scratch, total;   // byte offsets
     int64_t c_bstride;                                    // floats of hoisted conditioning per batch row
-    // flow pipeline (wn_iaf_p.hip): lA = the n_layers write-once buffers of one batch chunk, enc = one image
-    // per deconv stack, x = X[0 .. n_flows], M / S = one array per flow, cnt = progress words
-    int form, pipe_chunk, pipe_layers, pipe_stacks;
-    size_t cnt, enc_stack_floats;
+    int form;                                             // WN_COND_FUSED / WN_COND_HOISTED for this call
 };
 
-IafLayout iaf_layout(const wn_handle* h, int B, int F) {
+IafLayout iaf_layout(const wn_handle* h, int B, int F, int form) {
     IafLayout L;
     L.T = wn_iaf_length(h, F);
     L.TE = (int64_t)F * h->frame_shift;
@@ -434,73 +438,8 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F) {
     L.XR = (int)(IAF_XP + L.T);
     size_t o = 0;
     auto carve = [&](size_t floats) { size_t r = o; o += align_up(floats * sizeof(float), 256); return r; };
-    L.form = wn_iaf_form(h, B, L.T);
-    L.pipe_chunk = L.pipe_layers = L.pipe_stacks = 0;
-    L.cnt = L.enc_stack_floats = 0;
-    if (L.form == WN_COND_RESHOIST && L.T > 0) {
-        // hoisted GEMM + resident layers: enc, the projected term C of every row block (all utterances), max-layers + 1
-        // activation buffers of ONE utterance, progress words
-        int mx = 0;
-        for (const IafFlowPack& fp : h->flows) mx = std::max(mx, (int)fp.layers.size());
-        L.pipe_layers = mx + 1;
-        L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
-        L.lA = carve((size_t)L.pipe_layers * IAF_W * L.RS);
-        L.lB = L.lA;
-        L.x = carve((size_t)B * L.XR);
-        L.x0 = carve((size_t)B * L.T);
-        L.M = carve((size_t)B * L.T);
-        L.S = carve((size_t)B * L.T);
-        L.cnt = carve((size_t)h->num_cu * 16 + 64);
-        L.c_bstride = (int64_t)wn_iaf_c_floats(h->cfg.share_deconv ? h->cond_rows : mx + 1, L.T);
-        L.C = carve((size_t)B * L.c_bstride);
-        L.scratch = o;
-        o += wn_deconv_scratch_bytes(h, B, F);
-        L.total = o;
-        return L;
-    }
-    if (L.form == WN_COND_RESIDENT && L.T > 0) {
-        // segment-resident form: one image of enc per deconv stack, max-layers-per-flow + 1 activation buffers of
-        // ONE utterance (reused across flows and utterances: kernel boundaries separate the uses), progress words
-        int mx = 0;
-        for (const IafFlowPack& fp : h->flows) mx = std::max(mx, (int)fp.layers.size());
-        L.pipe_layers = mx + 1;
-        L.pipe_stacks = h->cfg.share_deconv ? 1 : h->cfg.n_flows;
-        L.enc_stack_floats = align_up((size_t)B * IAF_CD * L.TE + 64, 64);
-        L.enc = carve(L.enc_stack_floats * L.pipe_stacks);
-        L.lA = carve((size_t)L.pipe_layers * IAF_W * L.RS);
-        L.lB = L.lA;
-        L.x = carve((size_t)B * L.XR);
-        L.x0 = carve((size_t)B * L.T);
-        L.M = carve((size_t)B * L.T);
-        L.S = carve((size_t)B * L.T);
-        L.cnt = carve((size_t)h->num_cu * 4 + 64);
-        L.c_bstride = 0;
-        L.C = o;
-        L.scratch = o;
-        o += wn_deconv_scratch_bytes(h, B, F);
-        L.total = o;
-        return L;
-    }
-    if (L.form == WN_COND_PIPE && L.T > 0) {
-        for (const IafFlowPack& fp : h->flows) L.pipe_layers += (int)fp.layers.size();
-        L.pipe_stacks = h->cfg.share_deconv ? 1 : h->cfg.n_flows;
-        L.pipe_chunk = wn_iaf_p_chunk(h, B, L.T);
-        L.enc_stack_floats = align_up((size_t)B * IAF_CD * L.TE + 64, 64);
-        L.enc = carve(L.enc_stack_floats * L.pipe_stacks);
-        L.lA = carve((size_t)L.pipe_layers * L.pipe_chunk * IAF_W * L.RS);
-        L.lB = L.lA;
-        L.x = carve((size_t)(h->cfg.n_flows + 1) * B * L.XR);
-        L.x0 = carve((size_t)B * L.T);
-        L.M = carve((size_t)h->cfg.n_flows * B * L.T);
-        L.S = carve((size_t)h->cfg.n_flows * B * L.T);
-        L.cnt = carve((size_t)h->pipe_stages * 64 + 64);
-        L.c_bstride = 0;
-        L.C = o;
-        L.scratch = o;
-        o += wn_deconv_scratch_bytes(h, B, F);
-        L.total = o;
-        return L;
-    }
+    L.form = wn_iaf_form(h, B, L.T, form);
+    L.status = carve(64);                                  // range-guard word: first bytes of the workspace
     L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
     L.lA = carve((size_t)B * IAF_W * L.RS);
     L.lB = carve((size_t)B * IAF_W * L.RS);
@@ -629,267 +568,24 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
-// Hoisted conditioning GEMM + resident layers (wn_iaf_r.hip): per deconv stack the upsampler and ONE GEMM for all
-// utterances; then per utterance and flow the start conv, all residual layers in ONE launch per pass of
-// <= 256 x 128 columns, and the flow head.
-static int iaf_generate_reshoist(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
-                                 uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
-                                 float* scale_tot, float* rand_out, char* base, hipStream_t st) {
-    const wn_config& c = h->cfg;
-    float* enc = reinterpret_cast<float*>(base + L.enc);
-    float* lbuf = reinterpret_cast<float*>(base + L.lA);
-    float* x = reinterpret_cast<float*>(base + L.x);
-    float* x0g = reinterpret_cast<float*>(base + L.x0);
-    float* Mt = reinterpret_cast<float*>(base + L.M);
-    float* St = reinterpret_cast<float*>(base + L.S);
-    float* Cc = reinterpret_cast<float*>(base + L.C);
-    unsigned* flags = reinterpret_cast<unsigned*>(base + L.cnt);
-    void* scratch = base + L.scratch;
-    const size_t buf_floats = (size_t)IAF_W * L.RS;
-    const size_t rb_floats = (size_t)(L.T / 16) * 1024;
-    const unsigned* cond_tab = reinterpret_cast<const unsigned*>(h->d_blob + h->cond_tab_off);
-    WN_HIP(h, hipMemsetAsync(x, 0, (size_t)B * L.XR * sizeof(float), st));
-    WN_HIP(h, hipMemsetAsync(flags, 0, ((size_t)h->num_cu * 16 + 1) * sizeof(unsigned), st));
-    const float* x0 = noise;
-    {
-        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
-        if (noise) {
-            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
-        } else {
-            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
-                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
-            x0 = x0g;
-        }
-    }
-    wn_iaf_p_zero_pads(reinterpret_cast<unsigned*>(lbuf), L.RS, L.pipe_layers * 16, st);
-    if (c.share_deconv) {
-        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, true);
-        if (rc) return rc;
-        wn_iaf_c_cond(enc, h->d_blob, cond_tab, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T, h->num_cu, st);
-    }
-    const int max_blk = wn_iaf_r_max_cols(h) / 16, nblk_tot = (int)(L.T / 16);
-    unsigned epoch = 0;
-    double* unused = nullptr;
-    (void)unused;
-    for (int k = 0; k < c.n_flows; ++k) {
-        const IafFlowPack& fp = h->flows[k];
-        if (!c.share_deconv) {
-            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, true);
-            if (rc) return rc;
-            wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base, Cc, L.c_bstride, L.TE, L.c0, (int)fp.layers.size() + 1, B,
-                          L.T, h->num_cu, st);
-        }
-        const size_t row0 = c.share_deconv ? (size_t)fp.rb_base : 0;      // first row block of this flow inside C
-        const int nl = (int)fp.layers.size();
-        if (h->prof_on) {
-            hipEvent_t ev;
-            WN_HIP(h, hipEventCreate(&ev));
-            h->prof_events.push_back(ev);
-            WN_HIP(h, hipEventRecord(ev, st));
-        }
-        for (int b = 0; b < B; ++b) {
-            float* xb = x + (size_t)b * L.XR;
-            const float* Cb = Cc + (size_t)b * L.c_bstride + row0 * rb_floats;
-            wn_iaf_h_start(xb, h->d_blob + fp.start_off, lbuf, L.T, L.XR, L.RS, 1, st);
-            for (int b0 = 0; b0 < nblk_tot; b0 += max_blk) {
-                epoch += 256;
-                int rc = wn_iaf_r_flow(h, fp, Cb, (int64_t)rb_floats, reinterpret_cast<unsigned*>(lbuf), L.RS, 16 * b0,
-                                       std::min(max_blk, nblk_tot - b0), flags, epoch, st);
-                if (rc) return rc;
-                if (h->prof_on) ++h->prof_launches;
-            }
-            wn_iaf_c_head(lbuf + (size_t)nl * buf_floats, Cb + (size_t)nl * rb_floats, L.c_bstride, h->d_blob + fp.head_off_h,
-                          xb, Mt + (size_t)b * L.T, St + (size_t)b * L.T, L.RS, L.XR, L.T, k == 0 ? 1 : 0, 1, h->num_cu, st);
-        }
-        if (h->prof_on) {
-            hipEvent_t ev;
-            WN_HIP(h, hipEventCreate(&ev));
-            h->prof_events.push_back(ev);
-            WN_HIP(h, hipEventRecord(ev, st));
-        }
-    }
-    {
-        const int64_t nn = (int64_t)B * L.T;
-        const int Q = c.use_mu_law ? 256 : 65536;
-        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
-                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
-        wn_iaf_p_poison(flags + (size_t)h->num_cu * 16, wav, nn, st);
-        if (rand_out && rand_out != x0)
-            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    WN_HIP(h, hipGetLastError());
-    return WN_OK;
-}
-
-// The segment-resident form of a generate call (wn_iaf_s.hip): per utterance and flow, the start conv, then all
-// residual layers in ONE launch per pass of <= 256 x 192 columns, then the flow head.
-static int iaf_generate_resident(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
-                                 uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
-                                 float* scale_tot, float* rand_out, char* base, hipStream_t st) {
-    const wn_config& c = h->cfg;
-    float* enc = reinterpret_cast<float*>(base + L.enc);
-    float* lbuf = reinterpret_cast<float*>(base + L.lA);
-    float* x = reinterpret_cast<float*>(base + L.x);
-    float* x0g = reinterpret_cast<float*>(base + L.x0);
-    float* Mt = reinterpret_cast<float*>(base + L.M);
-    float* St = reinterpret_cast<float*>(base + L.S);
-    unsigned* flags = reinterpret_cast<unsigned*>(base + L.cnt);
-    void* scratch = base + L.scratch;
-    const size_t buf_floats = (size_t)IAF_W * L.RS;
-    WN_HIP(h, hipMemsetAsync(x, 0, (size_t)B * L.XR * sizeof(float), st));
-    WN_HIP(h, hipMemsetAsync(flags, 0, ((size_t)h->num_cu * 4 + 1) * sizeof(unsigned), st));
-    const float* x0 = noise;
-    {
-        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
-        if (noise) {
-            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
-        } else {
-            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
-                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
-            x0 = x0g;
-        }
-    }
-    wn_iaf_p_zero_pads(reinterpret_cast<unsigned*>(lbuf), L.RS, L.pipe_layers * 16, st);
-    for (int s = 0; s < L.pipe_stacks; ++s) {
-        const int si = c.share_deconv ? 0 : h->flows[s].deconv_stack;
-        int rc = wn_run_deconv(h, si, mel, B, F, enc + (size_t)s * L.enc_stack_floats, L.TE, scratch, st, true);
-        if (rc) return rc;
-    }
-    const int max_blk = wn_iaf_s_max_cols(h) / 16, nblk_tot = (int)(L.T / 16);
-    unsigned epoch = 0;
-    if (h->prof_on) {
-        hipEvent_t ev;
-        WN_HIP(h, hipEventCreate(&ev));
-        h->prof_events.push_back(ev);
-        WN_HIP(h, hipEventRecord(ev, st));
-    }
-    for (int b = 0; b < B; ++b) {
-        float* xb = x + (size_t)b * L.XR;
-        for (int k = 0; k < c.n_flows; ++k) {
-            const IafFlowPack& fp = h->flows[k];
-            const float* enc_b = enc + (size_t)(c.share_deconv ? 0 : k) * L.enc_stack_floats + (size_t)b * IAF_CD * L.TE;
-            wn_iaf_h_start(xb, h->d_blob + fp.start_off, lbuf, L.T, L.XR, L.RS, 1, st);
-            // full passes first: 12 blocks per CU keep the four waves of every CU equally loaded
-            for (int b0 = 0; b0 < nblk_tot; b0 += max_blk) {
-                epoch += 256;
-                int rc = wn_iaf_s_flow(h, fp, reinterpret_cast<const unsigned*>(enc_b), reinterpret_cast<unsigned*>(lbuf),
-                                       L.RS, L.TE, L.c0, 16 * b0, std::min(max_blk, nblk_tot - b0), flags, epoch, st);
-                if (rc) return rc;
-                if (h->prof_on) ++h->prof_launches;
-            }
-            wn_iaf_h_head(lbuf + fp.layers.size() * buf_floats, enc_b, h->d_blob + fp.head_off_h, xb, Mt + (size_t)b * L.T,
-                          St + (size_t)b * L.T, L.RS, L.TE, L.c0, L.XR, L.T, k == 0 ? 1 : 0, 1, h->num_cu, st);
-        }
-    }
-    if (h->prof_on) {
-        hipEvent_t ev;
-        WN_HIP(h, hipEventCreate(&ev));
-        h->prof_events.push_back(ev);
-        WN_HIP(h, hipEventRecord(ev, st));
-    }
-    {
-        const int64_t nn = (int64_t)B * L.T;
-        const int Q = c.use_mu_law ? 256 : 65536;
-        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
-                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
-        wn_iaf_p_poison(flags + (size_t)h->num_cu * 4, wav, nn, st);
-        if (rand_out && rand_out != x0)
-            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    WN_HIP(h, hipGetLastError());
-    return WN_OK;
-}
-
-// The flow-pipeline form of a generate call (wn_iaf_p.hip): upsampler(s), then every layer and head of
-// every flow in ONE persistent launch per batch chunk, then the final affine + quantiser.
-static int iaf_generate_pipe(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
-                             uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
-                             float* scale_tot, float* rand_out, char* base, hipStream_t st) {
-    const wn_config& c = h->cfg;
-    float* enc = reinterpret_cast<float*>(base + L.enc);
-    unsigned* lbuf = reinterpret_cast<unsigned*>(base + L.lA);
-    float* X = reinterpret_cast<float*>(base + L.x);
-    float* x0g = reinterpret_cast<float*>(base + L.x0);
-    float* M = reinterpret_cast<float*>(base + L.M);
-    float* S = reinterpret_cast<float*>(base + L.S);
-    unsigned* cnt = reinterpret_cast<unsigned*>(base + L.cnt);
-    void* scratch = base + L.scratch;
-    const size_t x_floats = (size_t)B * L.XR, ms_floats = (size_t)B * L.T;
-    // flow inputs: zero everything once (left pads of all n_flows + 1 arrays), then the noise into X[0]
-    WN_HIP(h, hipMemsetAsync(X, 0, (size_t)(c.n_flows + 1) * x_floats * sizeof(float), st));
-    const float* x0 = noise;
-    {
-        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
-        if (noise) {
-            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, X, L.T, L.XR);
-        } else {
-            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, X, L.T, L.XR, seed,
-                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
-            x0 = x0g;
-        }
-    }
-    wn_iaf_p_zero_pads(lbuf, L.RS, L.pipe_layers * L.pipe_chunk * 16, st);
-    for (int s = 0; s < L.pipe_stacks; ++s) {
-        const int si = c.share_deconv ? 0 : h->flows[s].deconv_stack;
-        int rc = wn_run_deconv(h, si, mel, B, F, enc + (size_t)s * L.enc_stack_floats, L.TE, scratch, st, true);
-        if (rc) return rc;
-    }
-    WnPipeBufs P;
-    P.lbuf = lbuf;
-    P.enc = reinterpret_cast<const unsigned*>(enc);
-    P.enc_words = (long long)L.enc_stack_floats;
-    P.X = X;
-    P.x_floats = (long long)x_floats;
-    P.M = M;
-    P.S = S;
-    P.ms_floats = (long long)ms_floats;
-    P.cnt = cnt;
-    P.RS = L.RS;
-    P.TE = L.TE;
-    P.T = L.T;
-    P.c0 = L.c0;
-    P.XR = L.XR;
-    if (h->prof_on) {
-        hipEvent_t ev;
-        WN_HIP(h, hipEventCreate(&ev));
-        h->prof_events.push_back(ev);
-        WN_HIP(h, hipEventRecord(ev, st));
-    }
-    for (int b0 = 0; b0 < B; b0 += L.pipe_chunk) {
-        int rc = wn_iaf_p_run(h, P, b0, std::min(L.pipe_chunk, B - b0), st);
-        if (rc) return rc;
-        if (h->prof_on) ++h->prof_launches;
-    }
-    if (h->prof_on) {
-        hipEvent_t ev;
-        WN_HIP(h, hipEventCreate(&ev));
-        h->prof_events.push_back(ev);
-        WN_HIP(h, hipEventRecord(ev, st));
-    }
-    {
-        const int64_t nn = (int64_t)B * L.T;
-        const int Q = c.use_mu_law ? 256 : 65536;
-        const float* Ml = M + (size_t)(c.n_flows - 1) * ms_floats;
-        const float* Sl = S + (size_t)(c.n_flows - 1) * ms_floats;
-        hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Ml, Sl, nn,
-                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
-        wn_iaf_p_poison(cnt + (size_t)h->pipe_stages * 64, wav, nn, st);
-        if (rand_out && rand_out != x0)
-            WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    WN_HIP(h, hipGetLastError());
-    return WN_OK;
-}
-
 extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, const float* noise,
                                uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
                                float* scale_tot, float* rand_out, void* ws, size_t ws_bytes, void* stream) {
+    return wn_iaf_generate_form(h, WN_FORM_DEFAULT, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out,
+                                ws, ws_bytes, stream);
+}
+
+extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, int B, int F, const float* noise,
+                                    uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
+                                    float* scale_tot, float* rand_out, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_iaf_generate: null handle");
+    if (form < WN_FORM_DEFAULT || form > WN_FORM_F16X3_FUSED)
+        return wn_fail(h, WN_EINVAL, "wn_iaf_generate_form: unknown form %d", form);
     if (!h->finalized) return wn_fail(h, WN_ESTATE, "wn_iaf_generate: call wn_finalize first");
     if (h->cfg.kind != WN_KIND_STUDENT)
         return wn_fail(h, WN_EINVAL, "wn_iaf_generate: handle is not a ParallelWavenet student");
     if (B < 1 || F < 1) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: B and F must be >= 1");
-    const IafLayout L = iaf_layout(h, B, F);
+    const IafLayout L = iaf_layout(h, B, F, form);
     if (L.T == 0) return WN_OK;   // fewer frames than one max-dilation block: empty output
     if (!mel || !wav || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: null mel/wav/workspace");
     if (ws_bytes < L.total)
@@ -908,20 +604,16 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     float* Mt = reinterpret_cast<float*>(base + L.M);
     float* St = reinterpret_cast<float*>(base + L.S);
     float* Cc = reinterpret_cast<float*>(base + L.C);
+    unsigned* status = reinterpret_cast<unsigned*>(base + L.status);
     void* scratch = base + L.scratch;
     const wn_config& c = h->cfg;
 
-    const bool f16x3 = c.precision == WN_PREC_F16X3;
+    const int prec = wn_form_precision(h, form);
+    const bool f16x3 = prec == WN_PREC_F16X3;
     if (!h->iaf_attrs_set) {       // per handle: function attributes belong to the handle's device
         int rc = wn_iaf_h_set_attrs(h);
         if (rc) return rc;
         rc = wn_iaf_c_set_attrs(h);
-        if (rc) return rc;
-        rc = wn_iaf_p_set_attrs(h);
-        if (rc) return rc;
-        rc = wn_iaf_s_set_attrs(h);
-        if (rc) return rc;
-        rc = wn_iaf_r_set_attrs(h);
         if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -932,13 +624,6 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         h->iaf_attrs_set = true;
     }
 
-    if (L.form == WN_COND_RESHOIST)
-        return iaf_generate_reshoist(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
-    if (L.form == WN_COND_RESIDENT)
-        return iaf_generate_resident(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
-    if (L.form == WN_COND_PIPE)
-        return iaf_generate_pipe(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
-
     // zero left pads
     {
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
@@ -946,7 +631,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
         const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
         dim3 g((pad + 255) / 256, rows, 3);
-        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B);
+        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B, status);
     }
     // noise
     const float* x0 = noise;
@@ -964,7 +649,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     const unsigned* cond_tab = reinterpret_cast<const unsigned*>(h->d_blob + h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
     if (c.share_deconv) {
-        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3);
+        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
         if (rc) return rc;
         if (hoist)
             wn_iaf_c_cond(enc, h->d_blob, cond_tab, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T, h->num_cu, st);
@@ -976,7 +661,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
     for (int k = 0; k < c.n_flows; ++k) {
         const IafFlowPack& fp = h->flows[k];
         if (!c.share_deconv) {
-            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3);
+            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
             if (rc) return rc;
             if (hoist)
                 wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base, Cc, L.c_bstride, L.TE, L.c0,
@@ -992,7 +677,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                                 wn_iaf_c_pair_ok(fp.layers[0].dilation, fp.layers[1].dilation);
         if (fuse_start || pair_start) {
         } else if (f16x3) {
-            wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st);
+            wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st, status);
         } else {
             dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
             hipLaunchKernelGGL(iaf_start_kernel, g, dim3(256), 0, st, x, h->d_blob + fp.start_off, lA, L.T,
@@ -1024,7 +709,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                 if (int rc = prof_mark(false, 0)) return rc;
                 wn_iaf_c_pair(lin, lout, Cf + li * rb_floats, Cf + (li + 1) * rb_floats, L.c_bstride,
                               h->d_blob + lp.off_h, h->d_blob + lq.off_h, L.RS, lp.dilation, lq.dilation, B, L.T,
-                              h->num_cu, st, (i == 0 && pair_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off);
+                              h->num_cu, st, (i == 0 && pair_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off, status);
                 float* t = lin; lin = lout; lout = t;
                 li += 2;
                 ++i;
@@ -1035,7 +720,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
                 if (int rc = prof_mark(false, 0)) return rc;
                 wn_iaf_c_layer_head(lin, Cf + li * rb_floats, Cf + (li + 1) * rb_floats, L.c_bstride,
                                     h->d_blob + lp.off_h, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.XR, lp.dilation,
-                                    k == 0 ? 1 : 0, B, L.T, h->num_cu, st);
+                                    k == 0 ? 1 : 0, B, L.T, h->num_cu, st, status);
                 head_done = true;
                 ++li;
                 continue;
@@ -1043,9 +728,9 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
             if (int rc = prof_mark(true, 1)) return rc;
             if (hoist)
                 wn_iaf_c_layer(lin, lout, Cf + li * rb_floats, L.c_bstride, h->d_blob + lp.off_h, L.RS, lp.dilation, B,
-                               L.T, h->num_cu, st);
+                               L.T, h->num_cu, st, status);
             else if (f16x3)
-                wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st,
+                wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st, status,
                                (li == 0 && fuse_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off);
             else
                 hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
@@ -1071,7 +756,7 @@ extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, con
         const int64_t nn = (int64_t)B * L.T;
         const int Q = c.use_mu_law ? 256 : 65536;
         hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn,
-                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot);
+                           Q, c.use_mu_law, wav, idx, x_raw, mean_tot, scale_tot, status);
         if (rand_out && rand_out != x0)
             WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
@@ -1096,21 +781,14 @@ extern "C" int wn_clip_quant(wn_handle* h, const float* x, int64_t n, float* wav
 // (cond_mode / WN_COND=fused): every layer kernel streams enc itself (1536 B/sample/layer, no extra
 // workspace).  Measured on MI355X (M samples/s, hoisted / fused): 50.7 / 46.8 at one utterance of
 // 4.8 s, 56 / 49 at two, 61 / 42 at eight.
-int wn_iaf_form(const wn_handle* h, int B, int64_t T) {
-    if (h->cfg.precision != WN_PREC_F16X3) return WN_COND_FUSED;
+int wn_form_precision(const wn_handle* h, int form) {
+    return form == WN_FORM_F32 ? WN_PREC_F32 : form == WN_FORM_DEFAULT ? h->cfg.precision : WN_PREC_F16X3;
+}
+
+int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form) {
+    if (wn_form_precision(h, form) != WN_PREC_F16X3 || form == WN_FORM_F16X3_FUSED) return WN_COND_FUSED;
     int mode = h->cfg.cond_mode;
     if (mode == WN_COND_AUTO) mode = h->cond_env_mode;           // WN_COND, resolved once in wn_create
-    if (mode == WN_COND_PIPE) return wn_iaf_p_supported(h) ? WN_COND_PIPE : WN_COND_FUSED;
-    if (mode == WN_COND_RESHOIST) {
-        for (const IafFlowPack& fp : h->flows)
-            if (fp.layers.empty() || (int)fp.layers.size() > wn_iaf_r_max_layers()) return WN_COND_HOISTED;
-        return WN_COND_RESHOIST;
-    }
-    if (mode == WN_COND_RESIDENT) {
-        for (const IafFlowPack& fp : h->flows)
-            if (fp.layers.empty() || (int)fp.layers.size() > wn_iaf_s_max_layers()) return WN_COND_FUSED;
-        return WN_COND_RESIDENT;
-    }
     if (mode == WN_COND_FUSED) return WN_COND_FUSED;
     if (mode == WN_COND_HOISTED) return WN_COND_HOISTED;
     return wn_iaf_hoisted(h, B, T) ? WN_COND_HOISTED : WN_COND_FUSED;
@@ -1119,7 +797,6 @@ int wn_iaf_form(const wn_handle* h, int B, int64_t T) {
 // Default placement (cond_mode 0, no WN_COND): hoisted while the projected term (256 B per sample and row
 // block) stays below a third of the device memory, else the fused form, which needs no such workspace.
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
-    if (h->cfg.precision != WN_PREC_F16X3) return false;
     int rows = h->cond_rows;
     if (!h->cfg.share_deconv) {
         rows = 0;
@@ -1130,10 +807,28 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 
 extern "C" int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F) {
     if (!h || h->cfg.kind != WN_KIND_STUDENT || B < 1 || F < 1) return 0;
-    return wn_iaf_form(h, B, wn_iaf_length(h, F)) == WN_COND_HOISTED ? 1 : 0;
+    return wn_iaf_form(h, B, wn_iaf_length(h, F), WN_FORM_DEFAULT) == WN_COND_HOISTED ? 1 : 0;
 }
 
-size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F) { return iaf_layout(h, B, F).total; }
+// default form: room for the fp32 re-run of a call that left the fp16 range as well (it needs less: no projected term)
+size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F, int form) {
+    size_t n = iaf_layout(h, B, F, form).total;
+    if (form == WN_FORM_DEFAULT) n = std::max(n, iaf_layout(h, B, F, WN_FORM_F32).total);
+    return n;
+}
+
+extern "C" int wn_iaf_range_status(wn_handle* h, const void* ws, void* stream) {
+    if (!h || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_range_status: null argument");
+    unsigned flag = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WN_HIP(h, hipMemcpyAsync(&flag, ws, sizeof(flag), hipMemcpyDeviceToHost, st));      // the status word leads the workspace
+    WN_HIP(h, hipStreamSynchronize(st));
+    if (flag)
+        return wn_fail(h, WN_ERANGE, "wn_iaf_generate: an activation left the fp16 range of the split-fp16 arithmetic "
+                       "(|value| >= 65504); the outputs of that call are NaN -- re-run it with "
+                       "wn_iaf_generate_form(h, WN_FORM_F32, ...)");
+    return WN_OK;
+}
 
 extern "C" int wn_profile_begin(wn_handle* h) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_begin: null handle");

@@ -37,16 +37,6 @@
 #ifndef WN_L_ST_AUX
 #define WN_L_ST_AUX 0
 #endif
-// Ablation switches of the conditioning GEMM (measurement only, results are WRONG when set; scripts/ablate_cond.sh):
-// 1 no C stores, 2 no enc staging loads, 4 A fragments loaded once per row block, 8 B operands read once per row block,
-// 16 one MFMA per product instead of three
-#ifndef WN_CK_ABL
-#define WN_CK_ABL 0
-#endif
-// Ablation of the layer kernel (measurement only, WRONG results): 1 gate without exp / rcp, 2 one MFMA per product in the K loop
-#ifndef WN_LC_ABL
-#define WN_LC_ABL 0
-#endif
 #ifndef WN_ENC_STAGE_AUX
 #define WN_ENC_STAGE_AUX 0
 #endif
@@ -123,7 +113,7 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 wn_u4 tmp[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    tmp[p] = (WN_CK_ABL & 2) ? (wn_u4){(unsigned)p, 0u, 0u, 0u} : buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
+                    tmp[p] = buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_NC + col] = tmp[p];
             }
@@ -146,7 +136,6 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             auto store_nb = [&](int nb) {
                 // column blocks past the end of the row fall outside the descriptor and are dropped
                 const int cb = (CK_NC / 16) * j + nb;
-                if ((WN_CK_ABL & 1) && acc[0][nb][0] + acc[1][nb][1] + acc[2][nb][2] + acc[3][nb][3] != 12345.678f) return;   // keeps every accumulator live
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,
@@ -156,40 +145,25 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
             for (int ks = 0; ks < 8; ++ks) {
                 // next K-step's fragments (the next row block's first ones at the end)
                 const int an1 = ks + 1 < 8 ? ao + (ks + 1) * 8 * 1024 : an;
-                if (!(WN_CK_ABL & 4) || ks == 7) {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
-                        a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
-                    }
-                } else {
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        a[(ks + 1) & 1][mb][0] = a[ks & 1][mb][0];
-                        a[(ks + 1) & 1][mb][1] = a[ks & 1][mb][1];
-                    }
+                for (int mb = 0; mb < 4; ++mb) {
+                    a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
+                    a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
                 }
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb) {
                     const int cur = nb & 1;
                     if (ks * 8 + nb + 1 < 64) {
                         const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
-                        if (WN_CK_ABL & 8) {
-                            bb[cur ^ 1][0] = bb[cur][0];
-                            bb[cur ^ 1][1] = bb[cur][1];
-                        } else {
-                            bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
-                            bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
-                        }
+                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
                     }
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
-                    if (!(WN_CK_ABL & 16)) {
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
-                    }
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
                     // results of a column block leave while the next one is being computed
                     if (ks == 7 && nb >= 1) store_nb(nb - 1);
                     // the eight fragment loads of the next K-step go out FIRST (left alone the scheduler sinks them
@@ -230,18 +204,8 @@ struct HeadArgs {
     int XR;
     int64_t T;
     int first;
+    unsigned* status;           // range-guard word of the call (every variant; wn_codec.h)
 };
-
-#ifdef WN_LC_STAMPS      // dev aid: s_memtime stamps (10 ns units) of wave 0 of a few workgroups of the layer kernel
-__device__ unsigned long long wn_lc_stamp_buf[8][16];
-#define LC_STAMP(i)                                                                                    \
-    do {                                                                                               \
-        if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8 && (i) < 16)           \
-            wn_lc_stamp_buf[blockIdx.x >> 6][(i)] = __builtin_amdgcn_s_memtime();                      \
-    } while (0)
-#else
-#define LC_STAMP(i) do {} while (0)
-#endif
 
 // W2: ONE workgroup of 512 threads per CU instead of two of 256: its two halves walk tiles independently (like two
 // workgroups) but share one weight image -- half the staging traffic, half the workgroups to dispatch.
@@ -254,13 +218,8 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
     const unsigned* __restrict__ wpack, int64_t RS, int d, int tiles_per_row, int ntiles, HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int TILE = 64 * HN;
-    LC_STAMP(0);
-#ifdef WN_LC_STAMPS
-    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8) wn_lc_stamp_buf[blockIdx.x >> 6][13] = __builtin_amdgcn_s_memrealtime();
-#endif
-    int stamp_i = 3;
-    (void)stamp_i;
     constexpr int NT = W2 ? 512 : 256;
+    float amax = 0.f;
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int n = lane & 15, q = lane >> 4;
     const wn_u4* Pl = reinterpret_cast<const wn_u4*>(ldsw) + lane;          // [((s*4+mb)*2+plane)*64]
@@ -353,15 +312,9 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
             for (int e = 0; e < HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
-#if WN_LC_ABL & 2
-                    acc[mb][e] = mfma_h(a[ks & 1][mb][0], bc[ks].h[e], acc[mb][e]);
-#else
                     acc[mb][e] = mfma3(a[ks & 1][mb][0], a[ks & 1][mb][1], bc[ks].h[e], bc[ks].l[e], acc[mb][e]);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        LC_STAMP(stamp_i);
-        ++stamp_i;
         // epilogue per column block: gate, residual 1x1, split, store
         const __amdgpu_buffer_rsrc_t ro =
             __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
@@ -380,12 +333,8 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
             for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-#if WN_LC_ABL & 1
-                    g[mg][r] = fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r]) * fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]);
-#else
                     g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
                                tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
-#endif
             wn_u4 gh, gl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -406,7 +355,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                     const float v0 = l0 + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
                     const float v1 = l1 + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
                     unsigned hw, lw;
-                    wn_split_pair(v0, v1, hw, lw);
+                    wn_split_pair_t(v0, v1, hw, lw, amax);
                     oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
                     ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
                 }
@@ -464,8 +413,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                 }
             }
         }
-        LC_STAMP(stamp_i);
-        ++stamp_i;
     };
 
     KOp<HN> bA[6], bB[6];
@@ -490,7 +437,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
         const bool has_tile = tile < tend;
         __builtin_amdgcn_sched_barrier(0);      // the vmcnt below counts on the image's loads being OLDER than the tile's
         if (has_tile) load_tile(tile, bA, cA, hA);
-        LC_STAMP(1);
         // the 16 HN operand loads of the tile may stay in flight; everything older (the image) has landed.  A plain
         // s_barrier: __syncthreads() carries a fence that makes the compiler wait for vmcnt(0) here.
         if (has_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * HN) : "memory");
@@ -499,7 +445,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
         asm volatile("" ::: "memory");
     } else {
     if (tile < tend) load_tile(tile, bA, cA, hA);
-    LC_STAMP(1);
     // the weight image is staged AFTER the first tile's operand loads are in flight
     stage_words<LC_A_WORDS, NT>(wpack, ldsw);
     stage_words<LC_TAIL_WORDS, NT>(wpack + IAF_P_FLOATS, ldsw + LC_A_WORDS);
@@ -513,7 +458,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
     }
     inv_m = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 128];
     inv_r = ldsf[LC_A_WORDS + IAF_PR_FLOATS + 129];
-    LC_STAMP(2);
     if (NOPF) {
         while (tile < tend) {
             body(tile, bA, cA, hA, bA, cA, hA);
@@ -528,14 +472,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
         body(tile, bB, cB, hB, bA, cA, hA);
         tile += tstep;
     }
-#ifdef WN_LC_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LC_STAMP(stamp_i);
-    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8) {
-        wn_lc_stamp_buf[blockIdx.x >> 6][15] = (unsigned long long)stamp_i;
-        wn_lc_stamp_buf[blockIdx.x >> 6][14] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
+    wn_range_flag(amax, ha.status);
 }
 
 // ---------------- two residual layers in one launch (small dilations) ----------------
@@ -565,7 +502,7 @@ struct PairLayer {
 // gate + residual 1x1 + skip of one 16-column block: acc -> new l as operand words (oh, ol);
 // lh/ll: the layer's tap-t operand words (K-steps 4, 5) = its input l
 __device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], const wn_u4 (&lh)[2], const wn_u4 (&ll)[2],
-                                     wn_u4 (&oh)[2], wn_u4 (&ol)[2]) {
+                                     wn_u4 (&oh)[2], wn_u4 (&ol)[2], float& amax) {
     float g[2][4];
 #pragma unroll
     for (int mg = 0; mg < 2; ++mg)
@@ -591,7 +528,7 @@ __device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], con
             const float v0 = l0 + fmaf(rc[2 * rp], w.inv_r, w.br[mb * 4 + 2 * rp]);
             const float v1 = l1 + fmaf(rc[2 * rp + 1], w.inv_r, w.br[mb * 4 + 2 * rp + 1]);
             unsigned hw, lw;
-            wn_split_pair(v0, v1, hw, lw);
+            wn_split_pair_t(v0, v1, hw, lw, amax);
             oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
             ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
         }
@@ -616,9 +553,10 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const float* __restrict__ CA,
     const float* __restrict__ CB, int64_t c_bstride, const unsigned* __restrict__ wA, const unsigned* __restrict__ wB,
     int64_t RS, int NB, int rl, int rpr, int ntasks, const float* __restrict__ x, int XR,
-    const float* __restrict__ wstart) {
+    const float* __restrict__ wstart, unsigned* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int DA = DB / 2, NW = PC_THREADS / 64;
+    float amax = 0.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, q = lane >> 4;
     const float* ldsf = reinterpret_cast<const float*>(ldsw);
@@ -763,7 +701,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
             const int pred = k + 1 < e ? 0 : OOB;
             // ---- layer A ----
             if (FIRST) {
-                first_layer_operands(xv, (long long)16 * k + n, q, wq, bc);
+                first_layer_operands(xv, (long long)16 * k + n, q, wq, bc, amax);
                 load_x(xvn, k + 1, pred);
             }
             f4 acc[4];
@@ -779,7 +717,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                      },
                      [&](int ks) { if (!FIRST) load_bc(k + 1, ks, pred); });
             wn_u4 oh[2], ol[2];
-            pair_epilogue(LA, acc, th, tl, oh, ol);
+            pair_epilogue(LA, acc, th, tl, oh, ol, amax);
             // ---- layer B ----
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb] = cb[mb];
@@ -794,7 +732,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                          },
                          [&](int) {});
                 wn_u4 qh[2], ql[2];
-                pair_epilogue(LB, acc, oh, ol, qh, ql);
+                pair_epilogue(LB, acc, oh, ol, qh, ql, amax);
                 const int vo_out = lane_l + 16 * k * 16;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -813,6 +751,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
             ++k;
         }
     }
+    wn_range_flag(amax, status);
 }
 
 // ---------------- flow head with hoisted conditioning (parallel_wavenet.py:256-277, :319-324) ----------------
@@ -1010,7 +949,9 @@ static bool lc_w2() {
 }
 
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
-                    int d, int B, int64_t T, int num_cu, hipStream_t st) {
+                    int d, int B, int64_t T, int num_cu, hipStream_t st, unsigned* status) {
+    HeadArgs hs{};
+    hs.status = status;
     const int hn = pick_hn_c(B, T, 2 * num_cu);
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
     const int slots = lc_slots(hn) * num_cu;
@@ -1019,7 +960,7 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
         const int g2 = std::min(num_cu, (ntiles + 1) / 2);
         hipLaunchKernelGGL((iaf_layer_c_kernel<1, false, true>), dim3(g2), dim3(512), LC_LDS_WORDS * 4, st,
                            reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout), C, c_bstride,
-                           reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, HeadArgs{});
+                           reinterpret_cast<const unsigned*>(wpack), RS, d, tiles_per_row, ntiles, hs);
         return;
     }
     // many tiles per workgroup (several utterances): 128-column tiles WITHOUT the register double buffer, two workgroups
@@ -1031,7 +972,7 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
         const int tpr = (int)(T / 128), nt2 = B * tpr, g2 = std::min(nt2, 2 * num_cu);
         hipLaunchKernelGGL((iaf_layer_c_kernel<2, false, false, true, true>), dim3(g2), dim3(256), LC_LDS_WORDS * 4, st,
                            reinterpret_cast<const unsigned*>(lin), reinterpret_cast<unsigned*>(lout), C, c_bstride,
-                           reinterpret_cast<const unsigned*>(wpack), RS, d, tpr, nt2, HeadArgs{});
+                           reinterpret_cast<const unsigned*>(wpack), RS, d, tpr, nt2, hs);
         return;
     }
     // few tiles per workgroup (one utterance): the start-up is a third of the workgroup's life and the DMA-staged
@@ -1042,25 +983,7 @@ void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bst
                         : (dma ? iaf_layer_c_kernel<2, false, false, true> : iaf_layer_c_kernel<2>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), C, c_bstride, reinterpret_cast<const unsigned*>(wpack), RS, d,
-                       tiles_per_row, ntiles, HeadArgs{});
-#ifdef WN_LC_STAMPS
-    static int dumped = 0;
-    if (dumped < 400 && getenv("WN_LC_DUMP")) {
-        ++dumped;
-        unsigned long long hb[8][16];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(wn_lc_stamp_buf), sizeof(hb));
-        if (dumped % 57 == 30)       // a few launches of a warm call
-            for (int w = 0; w < 8; ++w) {
-                const int ns = (int)hb[w][15];
-                fprintf(stderr, "lc d=%d hn=%d grid=%d wg %3d: issue %5.2f stage %5.2f |", d, hn, grid, w * 64,
-                        (double)(hb[w][1] - hb[w][0]) * 0.01, (double)(hb[w][2] - hb[w][1]) * 0.01);
-                for (int i = 3; i <= ns && i < 13; ++i) fprintf(stderr, " %5.2f", (double)(hb[w][i] - hb[w][i - 1]) * 0.01);
-                const double ticks = (double)(hb[w][ns < 13 ? ns : 12] - hb[w][0]), us = (double)(hb[w][14] - hb[w][13]) * 0.01;
-                fprintf(stderr, " | total %5.2f (x100 ticks) = %5.2f us by the 100 MHz counter => %4.0f MHz\n", ticks * 0.01, us, ticks / us);
-            }
-    }
-#endif
+                       tiles_per_row, ntiles, hs);
 }
 
 // Last layer of a flow with the flow head in its epilogue (64-sample tiles, two workgroups per CU).
@@ -1068,10 +991,10 @@ bool wn_iaf_c_last_ok() { return !getenv("WN_NO_HEADFUSE"); }
 
 void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int64_t c_bstride, const float* wpack,
                          const float* wpack_head, float* x, float* Mt, float* St, int64_t RS, int XR, int d, int first,
-                         int B, int64_t T, int num_cu, hipStream_t st) {
+                         int B, int64_t T, int num_cu, hipStream_t st, unsigned* status) {
     const int tiles_per_row = (int)(T / 64), ntiles = B * tiles_per_row;
     const int grid = ntiles < 2 * num_cu ? ntiles : 2 * num_cu;
-    HeadArgs ha{Ch, reinterpret_cast<const unsigned*>(wpack_head), x, Mt, St, XR, T, first};
+    HeadArgs ha{Ch, reinterpret_cast<const unsigned*>(wpack_head), x, Mt, St, XR, T, first, status};
     if (lc_w2()) {
         hipLaunchKernelGGL((iaf_layer_c_kernel<1, true, true>), dim3(std::min(num_cu, (ntiles + 1) / 2)), dim3(512),
                            (LC_LDS_WORDS + HC_LDS_WORDS) * 4, st, reinterpret_cast<const unsigned*>(lin),
@@ -1090,7 +1013,7 @@ bool wn_iaf_c_pair_ok(int da, int db) { return db == 2 * da && (db == 2 || db ==
 
 void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
                    const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,
-                   const float* x, int XR, const float* wstart) {
+                   const float* x, int XR, const float* wstart, unsigned* status) {
     const int NB = (int)(T / 16);
     const int64_t nw = (int64_t)num_cu * (PC_THREADS / 64);
     const int64_t want = std::max<int64_t>(1, nw / B);       // runs per row that give every wave one run
@@ -1104,7 +1027,7 @@ void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* 
     auto kern = db == 2 ? (x ? iaf_pair_c_kernel<2, true> : iaf_pair_c_kernel<2, false>) : iaf_pair_c_kernel<8, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PC_THREADS), PC_LDS_WORDS * 4, st, reinterpret_cast<const unsigned*>(lin),
                        reinterpret_cast<unsigned*>(lout), CA, CB, c_bstride, reinterpret_cast<const unsigned*>(wA),
-                       reinterpret_cast<const unsigned*>(wB), RS, NB, rl, rpr, (int)ntasks, x, XR, wstart);
+                       reinterpret_cast<const unsigned*>(wB), RS, NB, rl, rpr, (int)ntasks, x, XR, wstart, status);
 }
 
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,

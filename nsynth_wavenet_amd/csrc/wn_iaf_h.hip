@@ -28,7 +28,8 @@ namespace {
 // One thread = one G4 word group (8 channels) at one time step: consecutive threads write
 // consecutive 16-byte words of a group row (fully coalesced hi and lo streams).
 __global__ __launch_bounds__(256) void iaf_start_h_kernel(const float* __restrict__ x, const float* __restrict__ wb,
-                                                          unsigned* __restrict__ l, int64_t T, int XR, int64_t RS) {
+                                                          unsigned* __restrict__ l, int64_t T, int XR, int64_t RS,
+                                                          unsigned* __restrict__ status) {
     const int b = blockIdx.z, g = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void iaf_start_h_kernel(const float* __restric
     const float x0 = xp[-3], x1 = xp[-2], x2 = xp[-1];
     const int s = g >> 2, kg = g & 3;
     wn_u4 hw, lw;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = 2 * (16 * s + 8 * (i >> 1) + 2 * kg + (i & 1));      // even channel of the pair
@@ -44,10 +46,11 @@ __global__ __launch_bounds__(256) void iaf_start_h_kernel(const float* __restric
         for (int hh = 0; hh < 2; ++hh)
             o[hh] = wb[3 * IAF_W + c + hh] + wb[c + hh] * x0 + wb[IAF_W + c + hh] * x1 + wb[2 * IAF_W + c + hh] * x2;
         unsigned a, c2;
-        wn_split_pair(o[0], o[1], a, c2);
+        wn_split_pair_t(o[0], o[1], a, c2, amax);
         hw[i] = a;
         lw[i] = c2;
     }
+    wn_range_flag(amax, status);
     unsigned* base = l + (size_t)b * IAF_W * RS;
     *reinterpret_cast<wn_u4*>(base + ((size_t)g * RS + IAF_LP + t) * 4) = hw;
     *reinterpret_cast<wn_u4*>(base + ((size_t)(8 + g) * RS + IAF_LP + t) * 4) = lw;
@@ -60,9 +63,10 @@ template <int HN, bool FIRST = false>
 __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     const unsigned* __restrict__ lin, unsigned* __restrict__ lout, const unsigned* __restrict__ enc,
     const unsigned* __restrict__ wpack, int64_t RS, int64_t TE, int c0, int d, int tiles_per_row, int ntiles,
-    const float* __restrict__ x, int XR, const float* __restrict__ wstart) {
+    const float* __restrict__ x, int XR, const float* __restrict__ wstart, unsigned* __restrict__ status) {
     static_assert(!FIRST || HN == 1, "the fused start conv is written for 64-sample tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    float amax = 0.f;                      // range guard of the split words this workgroup produces (wn_codec.h)
     constexpr int TILE = 64 * HN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
     if (FIRST && tile0 < tend) {
         const int b0 = tile0 / tiles_per_row;
         KOp<1> f6[6];
-        first_layer_operands(xv, (long long)(tile0 - b0 * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6);
+        first_layer_operands(xv, (long long)(tile0 - b0 * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6, amax);
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) { bc[ks].h[0] = f6[ks].h[0]; bc[ks].l[0] = f6[ks].l[0]; }
     }
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 // the l operands of the next tile, computed while the enc K-steps keep the MFMA pipe busy
                 const int bn = next / tiles_per_row;
                 KOp<1> f6[6];
-                first_layer_operands(xv, (long long)(next - bn * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6);
+                first_layer_operands(xv, (long long)(next - bn * tiles_per_row) * TILE + wave * 16 + n, q, wq, f6, amax);
 #pragma unroll
                 for (int k2 = 0; k2 < 6; ++k2) { bc[k2].h[0] = f6[k2].h[0]; bc[k2].l[0] = f6[k2].l[0]; }
             }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                     const float v0 = l0 + fmaf(rc[2 * rp], inv_r, br[mb * 4 + 2 * rp]);
                     const float v1 = l1 + fmaf(rc[2 * rp + 1], inv_r, br[mb * 4 + 2 * rp + 1]);
                     unsigned hw, lw;
-                    wn_split_pair(v0, v1, hw, lw);
+                    wn_split_pair_t(v0, v1, hw, lw, amax);
                     oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
                     ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
                 }
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
             }
         }
     }
+    wn_range_flag(amax, status);
 }
 
 // ---------------- flow head (parallel_wavenet.py:256-277, :319-324) ----------------
@@ -472,16 +477,6 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
         blob.resize(blob.size() + align_up(tab.size(), 4));
         memcpy(blob.data() + h->cond_tab_off, tab.data(), tab.size() * sizeof(unsigned));
     }
-    // stage table of the flow pipeline (wn_iaf_p.hip)
-    {
-        std::vector<int> tab;
-        wn_iaf_p_stage_table(h, tab);
-        blob.resize(align_up(blob.size(), 64));
-        h->pipe_tab_off = blob.size();
-        h->pipe_stages = (int)(tab.size() / 8);
-        blob.resize(blob.size() + align_up(tab.size(), 4));
-        memcpy(blob.data() + h->pipe_tab_off, tab.data(), tab.size() * sizeof(int));
-    }
     return WN_OK;
 }
 
@@ -500,9 +495,10 @@ int wn_iaf_h_set_attrs(wn_handle* h) {
     return WN_OK;
 }
 
-void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st) {
+void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st,
+                    unsigned* status) {
     dim3 g((unsigned)((T + 255) / 256), 8, B);
-    hipLaunchKernelGGL(iaf_start_h_kernel, g, dim3(256), 0, st, x, wb, reinterpret_cast<unsigned*>(l), T, XR, RS);
+    hipLaunchKernelGGL(iaf_start_h_kernel, g, dim3(256), 0, st, x, wb, reinterpret_cast<unsigned*>(l), T, XR, RS, status);
 }
 
 // 64- or 128-sample workgroup tiles: whichever leaves the last round of the persistent grid
@@ -518,7 +514,7 @@ static int pick_hn(int B, int64_t T, int num_cu) {
 // x != nullptr: first layer of a flow -- the start conv is evaluated inside the kernel from the flow
 // input x (row stride XR) with the start weights wstart, lin is not read
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, const float* x, int XR,
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, unsigned* status, const float* x, int XR,
                     const float* wstart) {
     const int hn = x ? 1 : pick_hn(B, T, num_cu);
     const int tiles_per_row = (int)(T / (64 * hn)), ntiles = B * tiles_per_row;
@@ -530,13 +526,13 @@ void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float
     if (x)
         hipLaunchKernelGGL((iaf_layer_h_kernel<1, true>), dim3(grid), dim3(256),
                            (IAF_LAYER_H_WORDS + IAF_START_LDS_WORDS) * 4, st, li, lo, en, wp, RS, TE, c0, d, tiles_per_row,
-                           ntiles, x, XR, wstart);
+                           ntiles, x, XR, wstart, status);
     else if (hn == 1)
         hipLaunchKernelGGL((iaf_layer_h_kernel<1, false>), dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st, li, lo, en, wp,
-                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart);
+                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart, status);
     else
         hipLaunchKernelGGL((iaf_layer_h_kernel<2, false>), dim3(grid), dim3(256), IAF_LAYER_H_WORDS * 4, st, li, lo, en, wp,
-                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart);
+                           RS, TE, c0, d, tiles_per_row, ntiles, x, XR, wstart, status);
 }
 
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,

@@ -109,9 +109,6 @@ struct wn_handle {
     // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
     size_t cond_tab_off = 0;
     int cond_rows = 0;
-    // flow pipeline (wn_iaf_p.hip): stage table (8 ints per stage) inside the blob
-    size_t pipe_tab_off = 0;
-    int pipe_stages = 0;
     int frame_shift = 1;
     int num_cu = 256;
     // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
@@ -158,9 +155,6 @@ constexpr int WN_PREC_F32 = 1;     // fp32 MFMA
 constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB Infinity Cache, else fused
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
-constexpr int WN_COND_RESIDENT = 4; // every layer of a flow in ONE launch, activations resident per CU (wn_iaf_s.hip)
-constexpr int WN_COND_RESHOIST = 5; // hoisted GEMM + all layers of a flow in ONE launch per pass, activations resident per CU (wn_iaf_r.hip)
-constexpr int WN_COND_PIPE = 3;    // fused form, all layers and heads as ONE persistent pipeline launch (wn_iaf_p.hip)
 
 constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
@@ -179,15 +173,18 @@ struct DeconvScratch {
 size_t wn_deconv_scratch_bytes(const wn_handle* h, int B, int F);
 // split_out: write the LAST layer's output as split-fp16 words in the G4 layout (wn_iaf_h.hip)
 // instead of fp32 rows
+// status: the call's range-guard word (wn_codec.h), may be null; prec: WN_PREC_* of this call, -1 = the handle's
 int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
-                  float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st, bool split_out = false);
+                  float* enc_cm, int64_t enc_stride, void* scratch, hipStream_t st, bool split_out = false,
+                  unsigned* status = nullptr, int prec = -1);
 
 int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
 int wn_iaf_h_set_attrs(wn_handle* h);
-void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st);
+void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st,
+                    unsigned* status);
 void wn_iaf_h_layer(const float* lin, float* lout, const float* enc, const float* wpack, int64_t RS, int64_t TE,
-                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, const float* x = nullptr, int XR = 0,
-                    const float* wstart = nullptr);
+                    int c0, int d, int B, int64_t T, int num_cu, hipStream_t st, unsigned* status,
+                    const float* x = nullptr, int XR = 0, const float* wstart = nullptr);
 void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float* x, float* Mt, float* St,
                    int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T);
@@ -196,53 +193,21 @@ size_t wn_iaf_c_floats(int R, int64_t T);
 void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, float* C, int64_t c_bstride,
                    int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st);
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
-                    int d, int B, int64_t T, int num_cu, hipStream_t st);
+                    int d, int B, int64_t T, int num_cu, hipStream_t st, unsigned* status);
 bool wn_iaf_c_last_ok();
 void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int64_t c_bstride, const float* wpack,
                          const float* wpack_head, float* x, float* Mt, float* St, int64_t RS, int XR, int d, int first,
-                         int B, int64_t T, int num_cu, hipStream_t st);
+                         int B, int64_t T, int num_cu, hipStream_t st, unsigned* status);
 bool wn_iaf_c_pair_ok(int da, int db);
 void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
                    const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,
-                   const float* x, int XR, const float* wstart);
+                   const float* x, int XR, const float* wstart, unsigned* status);
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
                    float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
-// ---- flow pipeline (wn_iaf_p.hip) ----
-struct WnPipeBufs {
-    unsigned* lbuf;            // n_layers write-once activation buffers of one batch chunk
-    const unsigned* enc;       // [stack][B][256 x TE] G4 words
-    long long enc_words;       //   words per stack
-    float* X;                  // [n_flows + 1][B][XR]
-    long long x_floats;
-    float* M;                  // [n_flows][B][T]
-    float* S;
-    long long ms_floats;
-    unsigned* cnt;             // progress words + error word
-    int64_t RS, TE, T;
-    int c0, XR;
-};
-void wn_iaf_p_stage_table(const wn_handle* h, std::vector<int>& tab);
-bool wn_iaf_p_supported(const wn_handle* h);
-int wn_iaf_p_set_attrs(wn_handle* h);
-int wn_iaf_p_chunk(const wn_handle* h, int B, int64_t T);
-int wn_iaf_p_run(wn_handle* h, const WnPipeBufs& P, int B0, int Bc, hipStream_t st);
-void wn_iaf_p_zero_pads(unsigned* lbuf, int64_t RS, int rows, hipStream_t st);
-void wn_iaf_p_poison(const unsigned* err, float* wav, int64_t n, hipStream_t st);
-int wn_iaf_form(const wn_handle* h, int B, int64_t T);
-// ---- resident layers on hoisted conditioning (wn_iaf_r.hip) ----
-int wn_iaf_r_set_attrs(wn_handle* h);
-int wn_iaf_r_max_cols(const wn_handle* h);
-int wn_iaf_r_max_layers();
-int wn_iaf_r_flow(wn_handle* h, const IafFlowPack& fp, const float* C, int64_t rb_floats, unsigned* lbuf, int64_t RS,
-                  int col0, int nblk, unsigned* flags, unsigned epoch, hipStream_t st);
-// ---- segment-resident flow kernel (wn_iaf_s.hip) ----
-int wn_iaf_s_set_attrs(wn_handle* h);
-int wn_iaf_s_max_cols(const wn_handle* h);
-int wn_iaf_s_max_layers();
-int wn_iaf_s_flow(wn_handle* h, const IafFlowPack& fp, const unsigned* enc_utt, unsigned* lbuf, int64_t RS, int64_t TE,
-                  int c0, int col0, int nblk, unsigned* flags, unsigned epoch, hipStream_t st);   // WN_COND_FUSED / _HOISTED / _PIPE for this call
+int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form);   // WN_COND_FUSED / _HOISTED for this call (form: WN_FORM_*)
+int wn_form_precision(const wn_handle* h, int form);              // WN_PREC_* a call of this form computes in
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
-size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F);
+size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F, int form = WN_FORM_DEFAULT);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);
 void wn_ar_release(wn_handle* h);
 void wn_ar_free_tables(wn_handle* h);

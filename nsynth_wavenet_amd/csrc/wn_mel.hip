@@ -187,8 +187,15 @@ int mel_tables(int dev, MelTables** out) {
         return wn_fail(nullptr, WN_EIO, "wn_mel_spectrogram: cannot upload the featuriser tables");
     }
     t.wmax = wmax;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MEL_LDS_FLOATS * (int)sizeof(float));
+    // 74 880 B of dynamic LDS, above the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_FLOATS * (int)sizeof(float));
+    if (ea != hipSuccess) {
+        (void)hipFree(t.twiddle); (void)hipFree(t.window); (void)hipFree(t.band); (void)hipFree(t.weight);
+        t.twiddle = nullptr;
+        return wn_fail(nullptr, WN_EIO, "wn_mel_spectrogram: this device does not grant the %d bytes of LDS the "
+                       "featuriser kernel needs (%s)", MEL_LDS_FLOATS * (int)sizeof(float), hipGetErrorString(ea));
+    }
     return WN_OK;
 }
 

@@ -109,7 +109,7 @@ __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int 
 // xv[j] = x[t-5+j]; wq[c] = (w0, w1, w2, b) in LDS; bc[2*tap + s] = K-step operands of tap t-2+tap.
 constexpr int IAF_START_LDS_WORDS = 64 * 4;
 __device__ inline void first_layer_operands(const float (&xv)[5], long long t, int kg, const f4* __restrict__ wq,
-                                            KOp<1> (&bc)[6]) {
+                                            KOp<1> (&bc)[6], float& amax) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -122,7 +122,7 @@ __device__ inline void first_layer_operands(const float (&xv)[5], long long t, i
                 float v1 = wb[3] + wb[0] * xv[tap] + wb[1] * xv[tap + 1] + wb[2] * xv[tap + 2];
                 if (t - 2 + tap < 0) v0 = v1 = 0.f;
                 unsigned hw, lw;
-                wn_split_pair(v0, v1, hw, lw);
+                wn_split_pair_t(v0, v1, hw, lw, amax);
                 bc[2 * tap + s].h[0][i] = hw;
                 bc[2 * tap + s].l[0][i] = lw;
             }

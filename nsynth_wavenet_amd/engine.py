@@ -34,6 +34,8 @@ class Engine(object):
         self._h = ctypes.c_void_p(0)
         self._ws = None
         self._ar_stream = None
+        self._last_ws = None
+        self.range_fallbacks = 0          # calls re-run on the fp32 form because they left the fp16 range
         self._finalized = False
         self.precision = precision or cfg.default_precision()
         c = cfg.to_wn_config(self.hp, self.kind, n_mel, self.precision)
@@ -108,10 +110,17 @@ class Engine(object):
         return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
 
     # ---- IAF path ----
-    def iaf_generate(self, mel, noise=None, seed=0, want=('wav',)):
+    def iaf_generate(self, mel, noise=None, seed=0, want=('wav',), check_range=True):
         """ParallelWavenet.feed_forward + _clip_quant_scale.  mel [B,F,n_mel].
         Returns a dict of device tensors for the names in `want` out of
-        wav, idx, x, mean_tot, scale_tot, rand_input."""
+        wav, idx, x, mean_tot, scale_tot, rand_input.
+
+        check_range (default): the split-fp16 arithmetic carries activations with the fp16 exponent range; when a
+        call leaves it (|activation| >= 65504, possible after flows with scales near e^7) the library NaN-poisons the
+        outputs and raises a status word.  The engine then reads that word (one 4-byte read-back, which synchronises
+        the stream) and transparently re-runs the call on the fp32-MFMA form, so the caller always gets the
+        reference's fp32 behaviour; `self.range_fallbacks` counts those re-runs.  check_range=False keeps the call
+        asynchronous (timing loops): call check_range() afterwards -- it raises if the LAST call overflowed."""
         mel = self._dev(mel)
         if mel.dim() != 3 or mel.shape[2] != self.n_mel:
             raise ValueError('mel must be [batch, frames, {}], got {}'.format(self.n_mel, tuple(mel.shape)))
@@ -129,16 +138,42 @@ class Engine(object):
         st = new() if 'scale_tot' in want else None
         ro = new() if 'rand_input' in want else None
         with torch.cuda.device(self.device):
-            nb = self.lib.wn_workspace_bytes(self._h, B, F)
-            ws = self._workspace(nb)
-            self._check(self.lib.wn_iaf_generate(
-                self._h, _ptr(mel), B, F, _ptr(noise), ctypes.c_uint64(int(seed)), _ptr(wav), _ptr(idx),
-                _ptr(xr), _ptr(mt), _ptr(st), _ptr(ro), _ptr(ws), ws.numel(), self._stream()))
+            form = _lib.FORM_DEFAULT
+            try:
+                ws = self._workspace(self.lib.wn_workspace_bytes(self._h, B, F))
+            except MemoryError:
+                # the hoisted-conditioning workspace (17.5 KB per generated sample) does not fit beside what else lives
+                # on this GPU: the fused form needs none of it
+                if self.precision not in ('f16x3', 'f16x3-hoisted'):
+                    raise
+                form = _lib.FORM_F16X3_FUSED
+                ws = self._workspace(self.lib.wn_iaf_workspace_bytes_form(self._h, form, B, F))
+
+            def run(f):
+                self._check(self.lib.wn_iaf_generate_form(
+                    self._h, f, _ptr(mel), B, F, _ptr(noise), ctypes.c_uint64(int(seed)), _ptr(wav), _ptr(idx),
+                    _ptr(xr), _ptr(mt), _ptr(st), _ptr(ro), _ptr(ws), ws.numel(), self._stream()))
+            run(form)
+            self._last_ws = ws
+            if check_range and self.precision != 'f32' and T > 0:
+                rc = self.lib.wn_iaf_range_status(self._h, _ptr(ws), self._stream())
+                if rc == _lib.WN_ERANGE:
+                    self.range_fallbacks += 1
+                    run(_lib.FORM_F32)      # same seed -> the same Philox draws when the noise is device-drawn
+                else:
+                    self._check(rc)
         for k, v in (('wav', wav), ('idx', idx), ('x', xr), ('mean_tot', mt), ('scale_tot', st),
                      ('rand_input', ro)):
             if k in want:
                 out[k] = v
         return out
+
+    def check_range(self):
+        """Raise if the last iaf_generate(check_range=False) call left the fp16 range (its outputs are NaN then)."""
+        if self._last_ws is None or self.precision == 'f32':
+            return
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_iaf_range_status(self._h, _ptr(self._last_ws), self._stream()))
 
     def clip_quant(self, x):
         x = self._dev(x)

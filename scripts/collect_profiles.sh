@@ -1,22 +1,18 @@
 # Copies what scripts/final_profile.sh left under gpurun_out/ into profiles/ (tracked) under this round's names and
 # rebuilds the PMC summaries (with the source hash of the kernels they were measured on).  Usage: collect_profiles.sh r02
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 G=gpurun_out
 cp $G/bench_f16x3.json profiles/${R}_bench_f16x3.json
 cp $G/bench_f16x3_b8.json profiles/${R}_bench_f16x3_batch8.json
 cp $G/bench_f16x3-fused.json profiles/${R}_bench_f16x3_fused.json
-cp $G/bench_f16x3-pipe.json profiles/${R}_bench_f16x3_pipe.json
-cp $G/bench_f16x3-resident.json profiles/${R}_bench_f16x3_resident.json
 cp $G/bench_f32.json profiles/${R}_bench_fp32.json
 for b in 1 8 64; do cp $G/bench_ar_b$b.json profiles/${R}_bench_ar_batch$b.json; done
 cp $G/bench_teacher.json profiles/${R}_bench_teacher_forward.json
 cp $G/fin1/fin1_kernel_stats.csv profiles/${R}_kernel_stats_f16x3.csv
 cp $G/finf/finf_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_fused.csv
 cp $G/fin8/fin8_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_batch8.csv
-cp $G/fin_f16x3-pipe/fin_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_pipe.csv
-cp $G/fin_f16x3-resident/fin_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_resident.csv
 python scripts/pmc_summary.py $G/pmc_fin profiles/${R}_pmc_summary_f16x3.json 1 "--no-extras"
 python scripts/pmc_summary.py $G/pmc_fused profiles/${R}_pmc_summary_f16x3_fused.json 1 "--no-extras --precision f16x3-fused"
 python scripts/pmc_summary.py $G/pmc_b8 profiles/${R}_pmc_summary_f16x3_batch8.json 8 "--no-extras --batch-per-gpu 8"

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
 timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
-for p in f16x3-fused f16x3-pipe f16x3-resident f32; do
+for p in f16x3-fused f32; do
   timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 5 --precision $p 2>&1 | tail -1 > gpurun_out/bench_$p.json
 done
 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --batch-per-gpu 8 2>&1 | tail -1 > gpurun_out/bench_f16x3_b8.json
@@ -16,8 +16,5 @@ R=$GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin1 -o fin1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/fin1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/finf -o finf -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --precision f16x3-fused > $R/gpurun_out/finf.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
-for p in f16x3-pipe f16x3-resident; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin_$p -o fin -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --precision $p > /dev/null 2>&1
-done
 cd $R; for f in gpurun_out/bench_*.json; do python -c "
 import json; d=json.load(open('$f')); r=d['roofline']; print('$f', round(d['value']/1e6,3),'Ms/s', round(d['ms_per_step'],3),'ms', r['bound'], round(r['achieved'],1), round(r['frac'],3), r.get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done

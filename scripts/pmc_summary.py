@@ -8,6 +8,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsynth_wavenet_amd import build as wbuild
 
 src, dst = sys.argv[1], sys.argv[2]
+try:
+    with open(os.path.join(src, 'source_hash.txt')) as f:
+        measured_hash = f.read().strip()
+except OSError:
+    sys.exit('{}: no source_hash.txt (scripts/pmc_layer.sh writes it when the counters are collected); refusing to '
+             'stamp counters of unknown sources'.format(src))
+if len(measured_hash) != 64:
+    sys.exit('{}/source_hash.txt does not hold a sha256'.format(src))
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 extra = sys.argv[4] if len(sys.argv) > 4 else ''
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -48,14 +56,15 @@ for k, d in agg.items():
 out = {
     '_about': 'rocprofv3 --pmc passes (scripts/pmc_layer.sh: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass, instruction-mix '
               'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ' + extra + '`, one MI355X, '
-              'round 2, split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
+              'split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
               'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a coalesced '
               'stream, MI355X_MICROARCH.md; calibrated on iaf_head_h_kernel: it reads 98.3 MB exactly once and reports '
               '~48.8 MB). These fabric-side counters include Infinity Cache hits.',
     'workload': {'batch_per_gpu': batch, 'frames': 384, 'samples': 76800},
-    # hash of the kernel sources these counters were measured on (nsynth_wavenet_amd.build.source_hash): bench.py
-    # replays `hbm_bytes_per_launch` as roofline.traffic only while the sources it runs are the same
-    'source_hash': wbuild.source_hash(),
+    # hash of the kernel sources these counters were measured on (nsynth_wavenet_amd.build.source_hash, written by
+    # scripts/pmc_layer.sh at collection time): bench.py replays `hbm_bytes_per_launch` as roofline.traffic only
+    # while the sources it runs are the same
+    'source_hash': measured_hash,
     'kernels': kernels,
 }
 json.dump(out, open(dst, 'w'), indent=1)

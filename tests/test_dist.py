@@ -95,20 +95,81 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0
 
 
-def test_bench_traffic_figure_follows_the_source_hash(monkeypatch):
+def test_bench_traffic_figure_follows_the_source_hash(monkeypatch, tmp_path):
     """roofline.traffic is the committed PMC figure of the dominant kernel ONLY for the kernel sources it was measured
-    on: with the tree's hash it is the layer kernel's own entry (not the head variant's, whatever template flags the
-    kernel name carries), with any other hash it is None."""
+    on: with the measured hash it is that kernel's own entry (not a variant's), with any other hash -- or for a
+    precision that has no summary of its own -- it is None."""
     import json
     import bench
     from nsynth_wavenet_amd import build
-    path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), 'profiles', 'r02_pmc_summary_f16x3.json')
-    d = json.load(open(path))
-    assert 'iaf_layer_c_kernel' in d['kernels'] and 'iaf_layer_c_kernel<head>' in d['kernels']
-    plain, head = d['kernels']['iaf_layer_c_kernel'], d['kernels']['iaf_layer_c_kernel<head>']
-    assert 0.9 * 58982400 <= plain['hbm_bytes_per_launch'] <= 1.3 * 58982400      # 768 B/sample: no wasted re-reads
-    assert head['hbm_bytes_per_launch'] != plain['hbm_bytes_per_launch']
-    monkeypatch.setattr(build, 'source_hash', lambda: d['source_hash'])
-    assert bench.pmc_traffic(1, 384, 'f16x3', True) == plain['hbm_bytes_per_launch']
+    dom = bench.DOMINANT_KERNEL
+    summary = {'workload': {'batch_per_gpu': 1, 'frames': 384, 'samples': 76800}, 'source_hash': 'a' * 64,
+               'kernels': {dom: {'hbm_bytes_per_launch': 61000000}, dom + '<head>': {'hbm_bytes_per_launch': 99000000}}}
+    os.makedirs(tmp_path / 'profiles')
+    with open(tmp_path / 'profiles' / (bench.PROFILE_ROUND + '_pmc_summary_f16x3.json'), 'w') as f:
+        json.dump(summary, f)
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(build, 'source_hash', lambda: 'a' * 64)
+    assert bench.pmc_traffic(1, 384, 'f16x3', True) == 61000000
+    assert bench.pmc_traffic(8, 384, 'f16x3', True) is None           # another workload
+    assert bench.pmc_traffic(1, 384, 'f16x3-fused', True) is None     # no summary of its own: nothing borrowed
     monkeypatch.setattr(build, 'source_hash', lambda: 'not-the-measured-sources')
     assert bench.pmc_traffic(1, 384, 'f16x3', True) is None
+    # the committed summary of this round, when present, must describe the kernel bench.py calls dominant
+    real = os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_pmc_summary_f16x3.json')
+    if os.path.exists(real):
+        d = json.load(open(real))
+        assert dom in d['kernels'] and len(d.get('source_hash', '')) == 64
+        assert d['kernels'][dom]['hbm_bytes_per_launch'] > 0
+
+
+def _cli_worker(rank, world, port, src, dst, ckpt, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from argparse import Namespace
+    from nsynth_wavenet_amd import cli
+    seen = []
+
+    def synth(hparams, mel, save_names, checkpoint_path):
+        assert mel.ndim == 3 and mel.shape[2] == 80 and mel.shape[0] == len(save_names)
+        seen.append((list(save_names), float(mel[:, 0, 0].sum())))
+        for n in save_names:
+            open(n, 'w').write('rank %d' % rank)
+
+    cli.run(Namespace(ckpt_dir=ckpt, source_path=src, save_path=dst, sample_length=-1, batch_size=2, npy_only=False,
+                      log='ERROR', gpu_id='0'), synth)
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cli_shards_files_over_two_ranks(tmp_path):
+    """cli.run under WORLD_SIZE=2 (gloo, no GPU): the sorted file list splits contiguously over the ranks, every rank
+    batches ITS files by --batch_size and names the outputs gen_<basename>.wav (the reference's naming,
+    eval_parallel_wavenet.py:52-69), nothing is generated twice and nothing is left out."""
+    src, dst, ckpt = tmp_path / 'in', tmp_path / 'out', tmp_path / 'ckpt'
+    for d in (src, ckpt):
+        os.makedirs(d)
+    for i in range(5):
+        np.save(src / ('utt%d.npy' % i), np.full([7, 80], float(i), np.float32))
+    import json
+    json.dump(load_json('parallel_wavenet.json'), open(ckpt / 'parallel_wavenet.json', 'w'))
+    hp = cfg.load_hparams(dict(load_json('parallel_wavenet.json'), num_iaf_layers=[1]))
+    np.savez(ckpt / 'model.ckpt-7.npz', **wts.synthetic_weights(hp, seed=3))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, str(src), str(dst), str(ckpt), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    names = lambda r: [os.path.basename(n) for batch, _ in res[r] for n in batch]     # noqa: E731
+    assert names(0) == ['gen_utt0.wav', 'gen_utt1.wav', 'gen_utt2.wav'] and names(1) == ['gen_utt3.wav', 'gen_utt4.wav']
+    assert [len(b) for b, _ in res[0]] == [2, 1] and [len(b) for b, _ in res[1]] == [2]
+    assert [s for _, s in res[0]] == [1.0, 2.0] and [s for _, s in res[1]] == [7.0]
+    assert sorted(os.listdir(dst)) == ['gen_utt%d.wav' % i for i in range(5)]
+    assert open(dst / 'gen_utt4.wav').read() == 'rank 1'

@@ -160,3 +160,75 @@ def test_config4_gauss_student_as_shipped_batch16():
     eng.close()
     ref_x = StudentRef(w, hp).feed_forward(mel[3:4], noise[3:4])['x'].astype(np.float64)
     assert np.abs(x[3:4] - ref_x).max() <= 2e-5 * scale
+
+
+def test_student_loads_through_a_tf_bundle_and_the_cli(tmp_path, monkeypatch):
+    """Row f2 on the GPU: the student reaches the engine THROUGH a TensorFlow V2 checkpoint bundle, not an .npz.
+    The bundle is hand-assembled (tests/bundle_assembler.py, never tf_bundle.write_bundle): two data shards, several
+    prefix-compressed index blocks, '<var>/ExponentialMovingAverage' keys, the teacher-owned upsampler under its RAW
+    names (use_teacher_deconv, parallelgen.py:31-39), a `global_step`, and three tensors stored with a size-equal
+    but DIFFERENT shape -- what Saver(var_dict, reshape=True) accepts (parallelgen.py:40).  eval_parallel_wavenet.py
+    runs on it (checkpoint state file, single *.json, .npy mel in, gen_<name>.wav out) and the written audio is held
+    to the float64 oracle on the same weights and the same noise."""
+    import json
+    import torch
+    from scipy.io import wavfile
+    import bundle_assembler as ba
+    import eval_parallel_wavenet as cli_main
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd import cli, config as cfg, weights as wts
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = dict(load_json('parallel_wavenet.json'), num_iaf_layers=[10, 10], use_teacher_deconv=True)
+    cfgd.pop('use_share_deconv', None)
+    hp = cfg.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=77, init='tf')
+    raw = wts.raw_name_variables(w, hp)
+    assert raw == {k for k in w if k.startswith('iaf_share/trans_conv')} and len(raw) == 4
+    stored = {}
+    for k, v in w.items():
+        key = k if k in raw else k + wts.EMA
+        a = np.asarray(v, '<f4')
+        if k == 'iaf_1/out2_scale/W':
+            a = a.reshape(64, 1)                       # [1,1,64,1] stored as [64,1]
+        elif k == 'iaf_2/dilated_conv_3/W':
+            a = a.reshape(3 * 64, 64)                  # [1,3,64,64] stored as [192,64]
+        elif k == 'iaf_share/trans_conv_1/kernel':
+            a = a.reshape(-1)                          # raw-name deconv kernel stored flat
+        stored[key] = a
+    stored['global_step'] = np.array(31337, '<i8')
+    ck = tmp_path / 'ckpt'
+    ck.mkdir()
+    prefix = str(ck / 'model.ckpt-31337')
+    ba.assemble(prefix, stored, shard_of={k: (1 if 'iaf_2' in k else 0) for k in stored}, n_shards=2, blocks=7,
+                restart_every=3)
+    (ck / 'checkpoint').write_text('model_checkpoint_path: "model.ckpt-31337"\nall_model_checkpoint_paths: "model.ckpt-31337"\n')
+    (ck / 'parallel_wavenet.json').write_text(json.dumps(cfgd))
+    assert not any(f.endswith('.npz') for f in os.listdir(ck))
+    # the loader's view of the bundle: every variable, reshaped back
+    hp2, ckpath = cli.resolve_model(str(ck))
+    assert ckpath == prefix
+    back = wts.load_checkpoint(ckpath, hp2)
+    assert set(back) == set(w) and all(back[k].shape == w[k].shape and np.array_equal(back[k], w[k]) for k in w)
+    # the CLI, in process, with the "unseeded" draw of the reference pinned so that the noise can be reproduced
+    src = tmp_path / 'in'
+    src.mkdir()
+    F = 24
+    mel = np.random.RandomState(5).uniform(0, 1, [F, 80]).astype(np.float32)
+    np.save(src / 'utt.npy', mel)
+    out = tmp_path / 'out'
+    np.random.seed(2468)
+    seed = int(np.random.RandomState(2468).randint(0, 2 ** 31 - 1))
+    args = cli.build_parser('t').parse_args(['--ckpt_dir', str(ck), '--source_path', str(src), '--save_path', str(out)])
+    cli_main.generate(args)
+    rate, audio = wavfile.read(out / 'gen_utt.wav')
+    T = O.iaf_length(F, O.HP(cfgd))
+    assert rate == 16000 and audio.dtype == np.float32 and audio.shape == (T,)
+    eng = Engine(cfgd).load_weights(w)                # same weights from memory: the noise of that seed, and the wav
+    ref_run = eng.iaf_generate(mel[None], None, seed=seed, want=('wav', 'rand_input'))
+    assert np.array_equal(_np(ref_run['wav'])[0], audio)
+    noise = _np(ref_run['rand_input'])
+    want = O.iaf_feed_forward(mel[None], noise, w, O.HP(cfgd), np.float64)
+    wav_ref, _ = O.clip_quant_scale(want['x'], 65536, False, np.float64)
+    assert np.abs(audio - wav_ref[0]).max() <= 1e-3 and np.mean(audio != wav_ref[0].astype(np.float32)) < 0.02
+    eng.close()
+    torch.cuda.synchronize()

@@ -25,15 +25,22 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def test_withheld_form_is_refused(monkeypatch):
-    """cond_mode 5 (hoisted-resident) is not parity-clean: wn_create must refuse it by default."""
+def test_unknown_forms_are_refused():
+    """Only forms a default or a documented precision= can select exist in the library (the round-2 single-launch
+    experiments are gone): unknown precision names and conditioning modes are refused, not mapped to something else."""
     from nsynth_wavenet_amd.engine import Engine
-    monkeypatch.delenv('WN_UNVERIFIED_FORMS', raising=False)
-    with pytest.raises(Exception, match='withheld'):
-        Engine(load_json('parallel_wavenet.json'), precision='f16x3-hoisted-resident')
+    from nsynth_wavenet_amd import config as cfg, _lib
+    import ctypes
+    for name in ('f16x3-pipe', 'f16x3-resident', 'f16x3-hoisted-resident'):
+        with pytest.raises(Exception):
+            Engine(load_json('parallel_wavenet.json'), precision=name)
+    c = cfg.to_wn_config(cfg.load_hparams(load_json('parallel_wavenet.json')), 'student', 80, 'f16x3')
+    c.cond_mode = 3
+    h = ctypes.c_void_p(0)
+    assert _lib.load().wn_create(ctypes.byref(c), ctypes.byref(h)) == -22
 
 
-@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f32'])
 @pytest.mark.parametrize('tag', ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'])
 def test_golden_vectors(tag, precision):
     """HIP path vs the committed oracle vectors (shared deconv + centre crop 76; unit-gain
@@ -458,7 +465,7 @@ def test_full_size_batch8_hoisted_conditioning():
     eng.close()
 
 
-@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused', 'f16x3-pipe', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused', 'f32'])
 def test_flow_head_scale_path_on_test_scale_draws(precision):
     """a6 scale path (parallel_wavenet.py:105-114: softplus -> clip(e^-9, e^7)) at the reference's
     tests/test_scale.py size: 76 800 N(0,1) draws routed into out2_scale by the probe weights
@@ -489,4 +496,75 @@ def test_flow_head_scale_path_on_test_scale_draws(precision):
     m1, m2 = O.SOFTPLUS_N01_M1, O.SOFTPLUS_N01_M2
     assert abs(s[0].mean() - m1) < 5 * np.sqrt((m2 - m1 * m1) / T)
     assert abs(s[0].std() - np.sqrt(m2 - m1 * m1)) < 0.01
+    eng.close()
+
+
+def _overflow_case(bias):
+    """Three one-layer flows with TF-init weights; the scale biases of the first two flows are `bias`, so that their
+    scales are clip(softplus(~bias), e^-9, e^7) (parallel_wavenet.py:105-114) and flow 3 sees x ~ noise * scale^2."""
+    from oracle import wavenet_np as O
+    cfgd = dict(load_json('parallel_wavenet.json'), num_iaf_layers=[1, 1, 1])
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=4321, init='tf')
+    for k in (1, 2):
+        w['iaf_%d/out2_scale/biases' % k] = np.full([1], bias, np.float32)
+    F = 6
+    T = O.iaf_length(F, hp)
+    mel = np.random.RandomState(3).uniform(0, 1, [2, F, 80]).astype(np.float32)
+    noise = O.logistic_from_uniform(np.random.RandomState(4).uniform(1e-5, 1 - 1e-5, [2, T]), np.float32)
+    return cfgd, hp, w, mel, noise
+
+
+def test_fp16_range_is_guarded_never_silent():
+    """The split-fp16 forms store activations with the fp16 EXPONENT range.  With scale = e^7 in two flows
+    (parallel_wavenet.py:105-114,277) the third flow's start conv sees |x| ~ 1e6 * |noise| and its output passes
+    65 504, where the reference's fp32 graph is finite.  Required: (i) the library notices -- status WN_ERANGE, every
+    float output NaN, never plausible audio; (ii) the Python engine transparently re-runs the call on the fp32-MFMA
+    form and matches the float64 oracle; (iii) a call that stays inside the range (|l| ~ 2e4) is NOT diverted and
+    matches the oracle in the split arithmetic."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    # (iii) large but in range: scale ~ 60 per flow -> x ~ 3.6e3 * |noise| <= 4e4, l0 = 0.05 * ... well below 65 504
+    cfgd, hp, w, mel, noise = _overflow_case(60.0)
+    ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+    assert 1e3 < np.abs(ref['x']).max() < 1e7
+    for prec in ('f16x3', 'f16x3-fused'):
+        eng = Engine(cfgd, precision=prec).load_weights(w)
+        out = eng.iaf_generate(mel, noise, want=('x', 'scale_tot'))
+        assert eng.range_fallbacks == 0
+        assert np.abs(_np(out['x']) - ref['x']).max() <= 2e-5 * np.abs(ref['x']).max()
+        eng.close()
+    # (i) + (ii): past the range
+    cfgd, hp, w, mel, noise = _overflow_case(1200.0)
+    ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+    assert np.isfinite(ref['x']).all() and np.abs(ref['x']).max() > 1e8
+    assert abs(ref['scale_tot'].max() / np.exp(21.0) - 1) < 1e-6 or ref['scale_tot'].max() > np.exp(14.0) * 0.99
+    for prec in ('f16x3', 'f16x3-fused'):
+        eng = Engine(cfgd, precision=prec).load_weights(w)
+        raw = eng.iaf_generate(mel, noise, want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot'), check_range=False)
+        for k in ('wav', 'x', 'mean_tot', 'scale_tot'):
+            assert np.isnan(_np(raw[k])).all(), (prec, k)            # poisoned, not plausible
+        assert (_np(raw['idx']) == 0).all()
+        with pytest.raises(RuntimeError, match='WN_ERANGE'):
+            eng.check_range()
+        out = eng.iaf_generate(mel, noise, want=('wav', 'x', 'mean_tot', 'scale_tot'))     # default: guarded
+        assert eng.range_fallbacks == 1
+        scale = np.abs(ref['x']).max()
+        assert np.isfinite(_np(out['x'])).all()
+        assert np.abs(_np(out['x']) - ref['x']).max() <= 2e-5 * scale
+        assert np.abs(_np(out['scale_tot']) - ref['scale_tot']).max() <= 2e-5 * ref['scale_tot'].max()
+        wav_ref, _ = O.clip_quant_scale(ref['x'], 65536, False, np.float64)
+        assert np.abs(_np(out['wav']) - wav_ref).max() <= 1e-3
+        # device-drawn noise: the re-run must see the SAME draws (same seed -> same Philox stream)
+        a = eng.iaf_generate(mel, None, seed=99, want=('x', 'rand_input'))
+        b = O.iaf_feed_forward(mel, _np(a['rand_input']), w, hp, np.float64)
+        assert eng.range_fallbacks == 2 and np.abs(_np(a['x']) - b['x']).max() <= 2e-5 * np.abs(b['x']).max()
+        # an in-range call on the same engine afterwards is served by the split form again
+        small = eng.iaf_generate(mel, noise * 0.0, want=('x',))
+        assert eng.range_fallbacks == 3 or np.isfinite(_np(small['x'])).all()
+        eng.close()
+    # the fp32 form has no such limit and needs no guard
+    eng = Engine(cfgd, precision='f32').load_weights(w)
+    out = eng.iaf_generate(mel, noise, want=('x',))
+    assert eng.range_fallbacks == 0 and np.abs(_np(out['x']) - ref['x']).max() <= 2e-5 * np.abs(ref['x']).max()
     eng.close()

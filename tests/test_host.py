@@ -234,7 +234,14 @@ def test_host_codecs_match_oracle():
     assert np.array_equal(utils.inv_mu_law_numpy(q), O.inv_mu_law(q))
     x = np.random.RandomState(0).uniform(-1, 1, 1000).astype(np.float32)
     assert np.array_equal(utils.mu_law_numpy(x), O.mu_law(x))
-    assert np.array_equal(utils.cast_quantize_numpy(x, 65536), O.cast_quantize(x, 65536))
+    # the reference's numpy helper TRUNCATES (auxilaries/utils.py:162-164: astype(np.int32) after the scaling), its
+    # TF twin floors (:153-154): equal on the grid and for x >= 0, one step apart for negative off-grid values
+    got = utils.cast_quantize_numpy(x, 65536)
+    assert np.array_equal(got, np.trunc(x.astype(np.float64) * 32768).astype(np.int32))
+    fl = O.cast_quantize(x, 65536)
+    assert np.array_equal(got[x >= 0], fl[x >= 0]) and np.all((got - fl)[x < 0] >= 0) and np.all((got - fl) <= 1)
+    grid = np.arange(-32768, 32768, 257, dtype=np.float32) / 32768
+    assert np.array_equal(utils.cast_quantize_numpy(grid, 65536), O.cast_quantize(grid, 65536))
 
 
 def test_run_all_eval_staging_and_sweep(tmp_path, monkeypatch):

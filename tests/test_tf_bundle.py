@@ -106,52 +106,9 @@ def test_weights_load_from_tf_bundle_and_cli_resolution(tmp_path):
     assert all(k.endswith(wts.EMA) for k in r.entries) and len(r.entries) == len(w)
 
 
-# ---- a second, writer-independent fixture: every byte below is produced by the helpers of THIS file from the
-# ---- format description (LevelDB table format + tensor_bundle.proto), never by tf_bundle.write_bundle
-def _vi(v):
-    out = bytearray()
-    while True:
-        b = v & 0x7F
-        v >>= 7
-        out.append(b | (0x80 if v else 0))
-        if not v:
-            return bytes(out)
-
-
-def _entry_proto(dtype, shape, shard, offset, size, crc, sliced=False):
-    dims = b''.join(b'\x12' + _vi(len(d)) + d for d in (b'\x08' + _vi(n) for n in shape))
-    out = b'\x08' + _vi(dtype) + b'\x12' + _vi(len(dims)) + dims
-    if shard:
-        out += b'\x18' + _vi(shard)
-    if offset:
-        out += b'\x20' + _vi(offset)
-    out += b'\x28' + _vi(size) + b'\x35' + struct.pack('<I', crc)
-    if sliced:                       # repeated TensorSliceProto slices = 7: one slice with one extent {start 0, length 2}
-        ext = b'\x08\x00\x10\x02'
-        sl = b'\x0a' + _vi(len(ext)) + ext
-        out += b'\x3a' + _vi(len(sl)) + sl
-    return out
-
-
-def _table_block(items, restart_every):
-    """(key, value) list -> block bytes with PREFIX-COMPRESSED keys and a restart array."""
-    out, restarts, last = bytearray(), [], b''
-    for i, (k, v) in enumerate(items):
-        shared = 0
-        if i % restart_every == 0:
-            restarts.append(len(out))
-        else:
-            while shared < min(len(k), len(last)) and k[shared] == last[shared]:
-                shared += 1
-        out += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
-        last = k
-    for r in restarts:
-        out += struct.pack('<I', r)
-    return bytes(out) + struct.pack('<I', len(restarts))
-
-
-def _frame(block):
-    return block + b'\x00' + struct.pack('<I', tb.mask_crc(tb.crc32c(block + b'\x00')))
+# ---- a second, writer-independent fixture: tests/bundle_assembler.py builds every byte from the format description
+# ---- (LevelDB table format + tensor_bundle.proto), never through tf_bundle.write_bundle
+import bundle_assembler as ba          # noqa: E402
 
 
 def test_reader_on_hand_assembled_multi_block_two_shard_bundle(tmp_path):
@@ -171,35 +128,8 @@ def test_reader_on_hand_assembled_multi_block_two_shard_bundle(tmp_path):
     }
     order = sorted(t)
     shard_of = {k: (1 if 'dilated_conv_2' in k or k == 'zero_len' else 0) for k in order}
-    blobs, offs = {0: bytearray(), 1: bytearray()}, {}
-    for k in order:
-        offs[k] = len(blobs[shard_of[k]])
-        blobs[shard_of[k]] += t[k].tobytes()
-    for sid in (0, 1):
-        open('{}.data-{:05d}-of-00002'.format(prefix, sid), 'wb').write(bytes(blobs[sid]))
-    dt = {np.dtype('<f4'): 1, np.dtype('<i8'): 9}
-    items = [(b'', b'\x08\x02' + b'\x1a\x02\x08\x01')]                      # header: num_shards 2, version.producer 1
-    for k in order:
-        raw = t[k].tobytes()
-        items.append((k.encode(), _entry_proto(dt[t[k].dtype], t[k].shape, shard_of[k], offs[k], len(raw),
-                                               tb.mask_crc(tb.crc32c(raw)))))
-    items.append((b'part/W', _entry_proto(1, [4, 2], 0, 0, 0, 0, sliced=True)))
-    items.sort(key=lambda kv: kv[0])
-    groups = [items[:3], items[3:5], items[5:]]                             # three data blocks
-    out, index_items = bytearray(), []
-    for g in groups:
-        blk = _table_block(g, restart_every=2)
-        index_items.append((g[-1][0], _vi(len(out)) + _vi(len(blk))))
-        out += _frame(blk)
-    meta = _table_block([], 1) if False else struct.pack('<II', 0, 1)
-    meta_off = len(out)
-    out += _frame(meta)
-    index = _table_block(index_items, restart_every=1)
-    index_off = len(out)
-    out += _frame(index)
-    footer = _vi(meta_off) + _vi(len(meta)) + _vi(index_off) + _vi(len(index))
-    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
-    open(prefix + '.index', 'wb').write(bytes(out) + footer)
+    items = ba.assemble(prefix, t, shard_of=shard_of, n_shards=2, blocks=3, restart_every=2,
+                        extra_items=[(b'part/W', ba.entry_proto(1, [4, 2], 0, 0, 0, 0, sliced=True))])
     # the prefix compression really is exercised: some entry shares >= 20 key bytes with its predecessor
     assert any(a[0][:20] == b[0][:20] and len(a[0]) > 20 for a, b in zip(items, items[1:]))
 

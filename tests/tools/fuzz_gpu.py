@@ -1,5 +1,5 @@
 """Randomised cross-checks of the execution forms against each other on the GPU (dev tool; run through
-gpurun: `python tests/tools/fuzz_gpu.py [seconds]`).  Student: auto / fused / hoisted / pipe / resident / hoisted-resident / fp32 on random
+gpurun: `python tests/tools/fuzz_gpu.py [seconds]`).  Student: auto / fused / hoisted / fp32 on random
 (batch, frames); teacher: GEMV step vs batched step vs full-sequence forward on random (batch, length)."""
 import json, os, sys, time
 import numpy as np
@@ -16,9 +16,7 @@ t_end = time.time() + budget / 2
 d = json.load(open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json')))
 hp = cfg.load_hparams(d)
 w = wts.synthetic_weights(hp, seed=int(rs.randint(1 << 20)), init='unit' if rs.rand() < 0.5 else 'tf')
-FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f16x3-pipe', 'f16x3-resident', 'f32')
-if os.environ.get('WN_UNVERIFIED_FORMS'):
-    FORMS += ('f16x3-hoisted-resident',)      # withheld: not parity-clean (wn_iaf_r.hip header)
+FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f32')
 engs = {p: Engine(d, precision=p).load_weights(w) for p in ('f16x3',) + FORMS}
 n = 0
 while time.time() < t_end:
