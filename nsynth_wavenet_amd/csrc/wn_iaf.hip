@@ -80,14 +80,20 @@ __global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __
 
 // zero the left pads of `rows` rows (row stride rs floats, pad floats each)
 // zero left pads of both activation buffers and of the flow input, one launch (blockIdx.z picks)
+// dl_rj > 0: lB holds the DL layout of wn_iaf_g.hip (32 residue rows of dl_rj 16-byte words per group row, 64 zero
+// words in front of each) instead of one left pad per row
 __global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
-                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status) {
+                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status,
+                                 int dl_rj) {
     const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (row == 0 && c == 0 && blockIdx.z == 0) *status = 0u;        // range-guard word of this call (wn_codec.h)
     if (blockIdx.z < 2) {
         float* p = blockIdx.z ? lB : lA;
-        if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
+        if (blockIdx.z == 1 && dl_rj > 0) {
+            // 32 x 64 words x 4 floats = pad floats again: float c -> residue c / 256, float c % 256 of its pad
+            if (row < rows && c < pad) p[(size_t)row * rs + (size_t)(c >> 8) * dl_rj * 4 + (c & 255)] = 0.f;
+        } else if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
     } else if (row < xrows && c < xpad) {
         x[(size_t)row * xrs + c] = 0.f;
     }
@@ -615,6 +621,8 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         if (rc) return rc;
         rc = wn_iaf_c_set_attrs(h);
         if (rc) return rc;
+        rc = wn_iaf_g_set_attrs(h);
+        if (rc) return rc;
         WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       IAF_LAYER_FLOATS * sizeof(float)));
@@ -624,6 +632,13 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         h->iaf_attrs_set = true;
     }
 
+    // The layer-group kernel (wn_iaf_g.hip) runs the hoisted form whenever every flow has a group plan and the
+    // decimated view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the
+    // whole call.  WN_NO_GROUPS=1: the per-layer / layer-pair launches (A/B measurements, cross-form tests).
+    const char* ng = getenv("WN_NO_GROUPS");
+    const bool no_groups = ng && atoi(ng) != 0;
+    const bool use_groups = f16x3 && L.form == WN_COND_HOISTED && h->groups_ok && !no_groups && L.T % 512 == 0 &&
+                            4 * IAF_LP == 32 * 64 * 4;
     // zero left pads
     {
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
@@ -631,7 +646,8 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
         const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
         dim3 g((pad + 255) / 256, rows, 3);
-        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B, status);
+        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B, status,
+                           use_groups ? 64 + (int)(L.T / 32) : 0);
     }
     // noise
     const float* x0 = noise;
@@ -646,13 +662,16 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         }
     }
     const bool hoist = L.form == WN_COND_HOISTED;
-    const unsigned* cond_tab = reinterpret_cast<const unsigned*>(h->d_blob + h->cond_tab_off);
+    auto blob_u = [&](size_t off) { return reinterpret_cast<const unsigned*>(h->d_blob + off); };
+    const unsigned* cond_tab = blob_u(h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
     if (c.share_deconv) {
         int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
         if (rc) return rc;
         if (hoist)
-            wn_iaf_c_cond(enc, h->d_blob, cond_tab, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T, h->num_cu, st);
+            wn_iaf_c_cond(enc, h->d_blob, cond_tab, blob_u(use_groups ? h->order_all_off : h->order_id_off),
+                          use_groups ? h->n_nat_all : h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T,
+                          h->num_cu, st);
     }
     const int tiles_per_row = (int)(L.T / 64);
     const int ntiles = B * tiles_per_row;
@@ -664,11 +683,42 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
             int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
             if (rc) return rc;
             if (hoist)
-                wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base, Cc, L.c_bstride, L.TE, L.c0,
+                wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base,
+                              use_groups ? blob_u(h->order_flow_off) + fp.rb_base : blob_u(h->order_id_off),
+                              use_groups ? h->n_nat_flow[k] : (int)fp.layers.size() + 1, Cc, L.c_bstride, L.TE, L.c0,
                               (int)fp.layers.size() + 1, B, L.T, h->num_cu, st);
         }
         // row blocks of this flow inside C (all flows when the deconv stack is shared)
         const float* Cf = Cc + (c.share_deconv ? (size_t)fp.rb_base * rb_floats : 0);
+        if (use_groups) {
+            // natural / decimated layer groups in LDS: lA natural, lB DL; the first group computes the start conv
+            // from x, the last one runs the flow head
+            float* gin = lA;
+            float* gout = lB;
+            if (h->prof_on) {
+                hipEvent_t ev;
+                WN_HIP(h, hipEventCreate(&ev));
+                h->prof_events.push_back(ev);
+                WN_HIP(h, hipEventRecord(ev, st));
+            }
+            for (size_t gi = 0; gi < fp.groups.size(); ++gi) {
+                const WnGroup& g = fp.groups[gi];
+                const bool lastg = gi + 1 == fp.groups.size();
+                wn_iaf_g_run(h, g, fp.layers.data(), Cf + (size_t)g.begin * rb_floats, rb_floats, L.c_bstride, gin, gout,
+                             L.RS, lastg ? 0 : fp.groups[gi + 1].kind, B, L.T, gi == 0 ? x : nullptr, L.XR,
+                             h->d_blob + fp.start_off, lastg, h->d_blob + fp.head_off_h, x, Mt, St, k == 0 ? 1 : 0, status,
+                             st);
+                std::swap(gin, gout);
+            }
+            if (h->prof_on) {
+                hipEvent_t ev;
+                WN_HIP(h, hipEventCreate(&ev));
+                h->prof_events.push_back(ev);
+                WN_HIP(h, hipEventRecord(ev, st));
+                h->prof_launches += (int64_t)fp.groups.size();
+            }
+            continue;
+        }
         // fused f16x3 form: the start conv runs inside the first layer kernel of the flow (dilation 1)
         const bool fuse_start = f16x3 && !hoist && !fp.layers.empty() && fp.layers[0].dilation == 1;
         // hoisted form: layer pairs with small dilations run as one launch (wn_iaf_c_pair); when the flow

@@ -22,17 +22,8 @@
 #include "wn_internal.h"
 #include "wn_codec.h"
 #include "wn_mfma_h.h"
+#include "wn_iaf_c.h"
 
-// Cache policy of the accesses to the hoisted term C: it is written once and read once, 1.3 GB per
-// utterance later, so both sides are marked non-temporal (aux bit 1 = nt) and do not displace the
-// residual stream in L2.  Measured at 8 utterances: the GEMM 3.85 -> 3.19 ms, the layer kernel
-// 103.7 -> 98.7 us.
-#ifndef WN_C_ST_AUX
-#define WN_C_ST_AUX 2
-#endif
-#ifndef WN_C_LD_AUX
-#define WN_C_LD_AUX 2
-#endif
 // Cache policy of the residual-stream stores of the layer kernels (aux: 2 = nt, 16 = sc1, 17 = sc0 sc1)
 #ifndef WN_L_ST_AUX
 #define WN_L_ST_AUX 0
@@ -45,29 +36,34 @@ namespace {
 
 constexpr int CK_NC = 128;                       // columns of one conditioning-GEMM task
 constexpr int CK_THREADS = 512;                  // 8 waves: two per SIMD hide each other's load / store latency
-constexpr int CK_LDS_BYTES = 2 * 32 * CK_NC * 16;   // enc tile: [plane][group][column] x 16 B
-constexpr int LC_A_WORDS = 6 * 4 * 2 * 256;      // dilated-conv fragments (K-steps 0-5)
-constexpr int LC_TAIL_WORDS = IAF_PR_FLOATS + 128 + 4;
-constexpr int LC_LDS_WORDS = LC_A_WORDS + LC_TAIL_WORDS;
-constexpr int HC_A_WORDS = 2 * 4 * 2 * 256;      // out1 fragments (K-steps 0-1)
-constexpr int HC_TAIL_WORDS = 64 * 3 + 4;
-constexpr int HC_LDS_WORDS = HC_A_WORDS + HC_TAIL_WORDS;
+constexpr int CK_NBS = 17;                       // 16-byte words per column block in the LDS tile (16 + 1 pad: the gather
+constexpr int CK_RS = 8 * CK_NBS;                //   of a decimated tile writes at stride 17, conflict-free like the reads)
+constexpr int CK_LDS_BYTES = 2 * 32 * CK_RS * 16;   // enc tile: [plane][group][column block][column] x 16 B
+constexpr int CK_DEC = 32;                       // decimation of the row blocks that feed a "dec" layer group (wn_iaf_g.hip)
 
 // ---------------- conditioning GEMM: C[rb] = Wcond[rb] (64 x 256) . enc (256 x T) ----------------
 // One task = (batch row, 128-column tile, chunk of row blocks).  The enc tile is staged once in
 // LDS as ready-made B operands; each wave then owns whole row blocks: its A fragments come
 // straight from L2 in fragment order (1 KB per wave load), every fragment is used against
 // the 8 column blocks of the tile, every B operand read from LDS feeds 12 MFMAs.
+// Row blocks come in two kinds (order[0 .. n_nat) natural, order[n_nat .. R) decimated; a chunk never mixes them):
+//   natural   -- tile j = columns [128 j, 128 j + 128), column block nb = 16 consecutive samples, C block 8 j + nb;
+//   decimated -- the layer (or head) runs in a decimated layer group of wn_iaf_g.hip, which walks the residue classes
+//                t = r (mod 32): tile j = (k = j / 4, rg = j % 4) = residues 8 rg .. 8 rg + 7 x decimated columns
+//                16 k .. 16 k + 15, column block nb = residue 8 rg + nb, C block (8 rg + nb) * (T / 512) + k.  The
+//                tile is GATHERED from enc in 128-byte runs (8 residues x 16 B) and holds the same 128 samples' worth
+//                of operands, so the MFMA loop is identical.
 __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
     const unsigned* __restrict__ enc, const unsigned* __restrict__ wblob, const unsigned* __restrict__ rb_off,
-    float* __restrict__ C, int64_t c_bstride, int64_t TE, int c0, int R, int CH, int nchunks, int tiles_per_row,
-    int ntiles, int64_t NCB) {
+    const unsigned* __restrict__ order, int n_nat, float* __restrict__ C, int64_t c_bstride, int64_t TE, int c0, int R,
+    int CH, int nch_nat, int nchunks, int tiles_per_row, int ntiles, int64_t NCB) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int NW = CK_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, q = lane >> 4;
     wn_u4* Bt = reinterpret_cast<wn_u4*>(ldsw);
     const int TE16 = (int)TE * 16;
+    const int NBD = (int)(NCB / CK_DEC);          // decimated column blocks per residue
 
     int first, end, step, t_lo;
     if ((gridDim.x & 7) == 0) {
@@ -87,26 +83,36 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
         const int tile = t_lo + task / nchunks, chunk = task % nchunks;
         const int b = tile / tiles_per_row;
         const int j = tile - b * tiles_per_row;
-        const int rb_end = min(R, (chunk + 1) * CH);
-        int rb = chunk * CH + wave;
+        const bool dec = chunk >= nch_nat;
+        const int p_lo = dec ? n_nat + (chunk - nch_nat) * CH : chunk * CH;
+        const int p_end = min(dec ? R : n_nat, p_lo + CH);
+        int pos = p_lo + wave;
         // first A fragments of this wave's first row block: in flight while the tile is staged
         wn_u4 a[2][4][2];
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7ffffff0, 0x00020000);
         {
-            const int ao = (int)rb_off[min(rb, R - 1)] * 4;
+            const int ao = (int)rb_off[order[min(pos, p_end - 1)]] * 4;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 a[0][mb][0] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 0) * 1024);
                 a[0][mb][1] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 1) * 1024);
             }
         }
-        // ---- stage the enc tile: 64 rows (plane, group) x 128 columns x 16 B ----
+        // ---- stage the enc tile: 64 rows (plane, group) x 8 column blocks x 16 columns x 16 B ----
         {
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(enc + (size_t)b * IAF_CD * TE), 0, IAF_CD * (int)TE * 4, 0x00020000);
             constexpr int RP = CK_THREADS / CK_NC;          // rows per pass
             const int col = threadIdx.x & (CK_NC - 1), rp = threadIdx.x / CK_NC;
-            const int vo = (c0 + CK_NC * j + col) * 16 + rp * TE16;
+            int src_col, dst;
+            if (dec) {       // thread = (decimated column col / 8, residue col % 8): 8 lanes fetch one 128-byte run
+                src_col = CK_DEC * (16 * (j >> 2) + (col >> 3)) + 8 * (j & 3) + (col & 7);
+                dst = (col & 7) * CK_NBS + (col >> 3);
+            } else {
+                src_col = CK_NC * j + col;
+                dst = (col >> 4) * CK_NBS + (col & 15);
+            }
+            const int vo = (c0 + src_col) * 16 + rp * TE16;
             __syncthreads();                      // previous task's operand reads are done
 #pragma unroll
             for (int c4 = 0; c4 < 64 / RP / 4; ++c4) {
@@ -115,12 +121,13 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 for (int p = 0; p < 4; ++p)
                     tmp[p] = buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_NC + col] = tmp[p];
+                for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_RS + dst] = tmp[p];
             }
             __syncthreads();
         }
-        for (; rb < rb_end; rb += NW) {
-            const int ao = (int)rb_off[rb] * 4, an = (int)rb_off[min(rb + NW, R - 1)] * 4;
+        for (; pos < p_end; pos += NW) {
+            const int rb = (int)order[pos];
+            const int ao = (int)rb_off[rb] * 4, an = (int)rb_off[order[min(pos + NW, p_end - 1)]] * 4;
             const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(C + (size_t)b * c_bstride + ((size_t)rb * NCB) * 1024), 0, (int)NCB * 4096, 0x00020000);
             f4 acc[4][8];
@@ -130,12 +137,12 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = (f4){0.f, 0.f, 0.f, 0.f};
             // B operands one (K-step, column block) ahead of the MFMAs that use them
             wn_u4 bb[2][2];
-            bb[0][0] = Bt[q * CK_NC + n];
-            bb[0][1] = Bt[(32 + q) * CK_NC + n];
+            bb[0][0] = Bt[q * CK_RS + n];
+            bb[0][1] = Bt[(32 + q) * CK_RS + n];
             __builtin_amdgcn_sched_barrier(0);     // not part of the first K-step's (2 LDS reads, 12 MFMAs) groups
             auto store_nb = [&](int nb) {
                 // column blocks past the end of the row fall outside the descriptor and are dropped
-                const int cb = (CK_NC / 16) * j + nb;
+                const int cb = dec ? (8 * (j & 3) + nb) * NBD + (j >> 2) : (CK_NC / 16) * j + nb;
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                     const int cur = nb & 1;
                     if (ks * 8 + nb + 1 < 64) {
                         const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
-                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_NC + 16 * nb1 + n];
-                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_NC + 16 * nb1 + n];
+                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_RS + CK_NBS * nb1 + n];
+                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_RS + CK_NBS * nb1 + n];
                     }
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
@@ -184,10 +191,6 @@ struct CSrc {
     int vo[3];
     int vc;
 };
-
-__device__ inline f4 buf_ldf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, WN_C_LD_AUX));
-}
 
 // ---------------- residual layer with hoisted conditioning ----------------
 // Same contraction as iaf_layer_h_kernel minus its eight enc K-steps: the accumulators start
@@ -490,50 +493,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
 // (start conv fused in, see first_layer_operands).
 constexpr int PC_THREADS = 512;
 constexpr int PC_LDS_WORDS = 2 * LC_LDS_WORDS + IAF_START_LDS_WORDS;
-
-struct PairLayer {
-    const wn_u4* Pl;
-    const wn_u4* PRl;
-    const float* bg;
-    const float* br;
-    float inv_m, inv_r;
-};
-
-// gate + residual 1x1 + skip of one 16-column block: acc -> new l as operand words (oh, ol);
-// lh/ll: the layer's tap-t operand words (K-steps 4, 5) = its input l
-__device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], const wn_u4 (&lh)[2], const wn_u4 (&ll)[2],
-                                     wn_u4 (&oh)[2], wn_u4 (&ol)[2], float& amax) {
-    float g[2][4];
-#pragma unroll
-    for (int mg = 0; mg < 2; ++mg)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            g[mg][r] = sigmoidf_(fmaf(acc[mg][r], w.inv_m, w.bg[mg * 4 + r])) *
-                       tanhf_(fmaf(acc[mg + 2][r], w.inv_m, w.bg[(mg + 2) * 4 + r]));
-    wn_u4 gh, gl;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        unsigned hw, lw;
-        wn_split_pair(g[i >> 1][(i & 1) * 2], g[i >> 1][(i & 1) * 2 + 1], hw, lw);
-        gh[i] = hw;
-        gl[i] = lw;
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const f4 rc = mfma3(w.PRl[(mb * 2 + 0) * 64], w.PRl[(mb * 2 + 1) * 64], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {
-            float l0, l1;
-            wn_join_pair(lh[mb >> 1][(mb & 1) * 2 + rp], ll[mb >> 1][(mb & 1) * 2 + rp], l0, l1);
-            const float v0 = l0 + fmaf(rc[2 * rp], w.inv_r, w.br[mb * 4 + 2 * rp]);
-            const float v1 = l1 + fmaf(rc[2 * rp + 1], w.inv_r, w.br[mb * 4 + 2 * rp + 1]);
-            unsigned hw, lw;
-            wn_split_pair_t(v0, v1, hw, lw, amax);
-            oh[mb >> 1][(mb & 1) * 2 + rp] = hw;
-            ol[mb >> 1][(mb & 1) * 2 + rp] = lw;
-        }
-    }
-}
 
 // column shift by SH (1..16) of a block's words: lane n gets cur[n - SH], or prev[n - SH + 16]
 template <int SH>
@@ -913,30 +872,35 @@ int wn_iaf_c_set_attrs(wn_handle* h) {
 // floats of C per batch row for R row blocks over T samples
 size_t wn_iaf_c_floats(int R, int64_t T) { return (size_t)R * (size_t)(T / 16) * 1024; }
 
-// Conditioning GEMM of the R row blocks listed in rb_off (word offsets of their 8-K-step
-// fragment arrays inside the weight blob) over enc columns [c0, c0+T).
-void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, float* C, int64_t c_bstride,
-                   int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st) {
+// Conditioning GEMM of the R row blocks listed in rb_off (word offsets of their 8-K-step fragment arrays inside the
+// weight blob) over enc columns [c0, c0+T).  order: the row-block indices, the n_nat natural ones first, then the
+// decimated ones (n_nat == R: every row block in natural column order).
+void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, const unsigned* order, int n_nat,
+                   float* C, int64_t c_bstride, int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st) {
     const int tiles_per_row = (int)((T + CK_NC - 1) / CK_NC), ntiles = B * tiles_per_row;
     constexpr int NW = CK_THREADS / 64;
-    // split the row blocks into chunks so that the persistent grid ends its last round full
-    int best_n = 1;
+    const int n_dec = R - n_nat;
+    // split each kind's row blocks into chunks of CH so that the persistent grid ends its last round full
+    int best_ch = (std::max(n_nat, n_dec) + NW - 1) / NW * NW;
     double best_cost = 1e30;
-    for (int nch = 1; nch <= 16; ++nch) {
-        const int ch = ((R + nch - 1) / nch + NW - 1) / NW * NW;
-        if (nch > 1 && (nch - 1) * ch >= R) continue;
+    for (int ch = NW; ch <= (std::max(n_nat, n_dec) + NW - 1) / NW * NW; ch += NW) {
+        const int nch = (n_nat + ch - 1) / ch + (n_dec + ch - 1) / ch;
+        // work of one tile: staging per chunk + one sub-round per NW row blocks of each chunk
+        double per_tile = 0.5 * nch;
+        for (int k = 0; k < 2; ++k)
+            for (int left = k ? n_dec : n_nat; left > 0; left -= ch) per_tile += (std::min(left, ch) + NW - 1) / NW;
         const int64_t rounds = ((int64_t)ntiles * nch + num_cu - 1) / num_cu;
-        const double cost = (double)rounds * (ch / NW + 0.5);    // +0.5: staging the enc tile
-        if (cost < best_cost) { best_cost = cost; best_n = nch; }
+        const double cost = (double)rounds * per_tile / nch;
+        if (cost < best_cost) { best_cost = cost; best_ch = ch; }
     }
-    if (const char* e = getenv("WN_COND_NCH")) best_n = std::max(1, atoi(e));
-    const int ch = ((R + best_n - 1) / best_n + NW - 1) / NW * NW;
-    const int nchunks = (R + ch - 1) / ch;
+    if (const char* e = getenv("WN_COND_CH")) best_ch = std::max(NW, atoi(e) / NW * NW);
+    const int ch = best_ch;
+    const int nch_nat = (n_nat + ch - 1) / ch, nchunks = nch_nat + (n_dec + ch - 1) / ch;
     const int64_t ntasks = (int64_t)ntiles * nchunks;
     const int grid = (int)std::min<int64_t>(ntasks, num_cu);
     hipLaunchKernelGGL(iaf_cond_h_kernel, dim3(grid), dim3(CK_THREADS), CK_LDS_BYTES, st,
-                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wblob), rb_off, C,
-                       c_bstride, TE, c0, R, ch, nchunks, tiles_per_row, ntiles, T / 16);
+                       reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wblob), rb_off, order,
+                       n_nat, C, c_bstride, TE, c0, R, ch, nch_nat, nchunks, tiles_per_row, ntiles, T / 16);
 }
 
 // workgroups per CU of the hoisted layer / head kernels (57 KB of LDS; the 128-column variant

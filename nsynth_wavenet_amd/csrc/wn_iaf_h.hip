@@ -477,6 +477,50 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
         blob.resize(blob.size() + align_up(tab.size(), 4));
         memcpy(blob.data() + h->cond_tab_off, tab.data(), tab.size() * sizeof(unsigned));
     }
+    // launch plan of the layer-group kernel (wn_iaf_g.hip) and the row-block orders the conditioning GEMM needs
+    // for it: natural row blocks first, then the ones a decimated group (or its flow head) consumes
+    {
+        h->groups_ok = true;
+        for (IafFlowPack& fp : h->flows) {
+            std::vector<int> dil;
+            for (const IafLayerPack& lp : fp.layers) dil.push_back(lp.dilation);
+            if (!wn_iaf_g_plan(dil, fp.groups)) { fp.groups.clear(); h->groups_ok = false; }
+        }
+        if (!h->groups_ok) for (IafFlowPack& fp : h->flows) fp.groups.clear();
+        const int R = h->cond_rows;
+        std::vector<unsigned> id(R), all, flw(R);
+        std::vector<unsigned> all_dec;
+        h->n_nat_flow.assign(c.n_flows, 0);
+        for (int i = 0; i < R; ++i) id[i] = (unsigned)i;
+        for (int k = 0; k < c.n_flows; ++k) {
+            const IafFlowPack& fp = h->flows[k];
+            const int nl = (int)fp.layers.size();
+            std::vector<int> kind(nl + 1, 0);
+            for (const WnGroup& g : fp.groups)
+                for (int i = g.begin; i < g.end; ++i) kind[i] = g.kind;
+            kind[nl] = fp.groups.empty() ? 0 : fp.groups.back().kind;      // the head runs inside the flow's last group
+            std::vector<unsigned> loc_nat, loc_dec;
+            for (int i = 0; i <= nl; ++i) (kind[i] ? loc_dec : loc_nat).push_back((unsigned)i);
+            h->n_nat_flow[k] = (int)loc_nat.size();
+            for (unsigned v : loc_nat) all.push_back(fp.rb_base + v);
+            for (unsigned v : loc_dec) all_dec.push_back(fp.rb_base + v);
+            size_t o = fp.rb_base;
+            for (unsigned v : loc_nat) flw[o++] = v;
+            for (unsigned v : loc_dec) flw[o++] = v;
+        }
+        h->n_nat_all = (int)all.size();
+        all.insert(all.end(), all_dec.begin(), all_dec.end());
+        auto put = [&](const std::vector<unsigned>& t) {
+            blob.resize(align_up(blob.size(), 64));
+            const size_t off = blob.size();
+            blob.resize(blob.size() + align_up(t.size(), 4));
+            memcpy(blob.data() + off, t.data(), t.size() * sizeof(unsigned));
+            return off;
+        };
+        h->order_id_off = put(id);
+        h->order_all_off = put(all);
+        h->order_flow_off = put(flw);
+    }
     return WN_OK;
 }
 

@@ -37,6 +37,14 @@ struct DeconvStackPack {
     std::vector<DeconvLayerPack> layers;
 };
 
+// launch group of wn_iaf_g.hip
+struct WnGroup {
+    int kind = 0;          // 0 natural time base, 1 decimated by 32
+    int begin = 0, end = 0;   // layers [begin, end) of the flow
+    int halo_cols = 0;     // 2 * sum of the (local) dilations
+    int n() const { return end - begin; }
+};
+
 // Student flow (wn_iaf.hip)
 struct IafLayerPack {
     size_t off;                        // fp32 path: LAYER_FLOATS floats: P | PR | bgate | bres
@@ -46,6 +54,7 @@ struct IafLayerPack {
 struct IafFlowPack {
     size_t start_off;                  // w[3][W] | b[W]
     std::vector<IafLayerPack> layers;
+    std::vector<WnGroup> groups;       // launch plan of wn_iaf_g.hip (empty: per-layer launches only)
     size_t head_off;                   // HEAD_FLOATS floats
     size_t head_off_h;                 // split-fp16 head pack
     int deconv_stack;                  // index into wn_handle::stacks
@@ -109,6 +118,13 @@ struct wn_handle {
     // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
     size_t cond_tab_off = 0;
     int cond_rows = 0;
+    // row-block orders of the conditioning GEMM (uint32 tables inside the blob, each cond_rows long): identity; all
+    // flows' natural row blocks first, then the decimated ones (shared deconv stack, wn_iaf_g.hip's plan); the same
+    // per flow with flow-local indices (private stacks).  n_nat: natural row blocks of the whole student / per flow
+    size_t order_id_off = 0, order_all_off = 0, order_flow_off = 0;
+    int n_nat_all = 0;
+    std::vector<int> n_nat_flow;
+    bool groups_ok = false;                   // every flow has a group plan
     int frame_shift = 1;
     int num_cu = 256;
     // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
@@ -156,7 +172,8 @@ constexpr int WN_COND_AUTO = 0;    // hoisted once enc + l outgrow the 256 MB In
 constexpr int WN_COND_FUSED = 1;   // inside every layer kernel (re-reads enc per layer)
 constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for all layers
 
-constexpr int IAF_LP = 1024;   // zero left pad of activation rows (>= 2 * max dilation)
+constexpr int IAF_LP = 2048;   // zero left pad of activation rows (>= 2 * max dilation; >= 32 * 64: the DL layout of
+                               // wn_iaf_g.hip keeps 64 zero columns in front of each of its 32 residue rows)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
 
 // ---- implemented in the .hip units ----
@@ -190,8 +207,8 @@ void wn_iaf_h_head(const float* lin, const float* enc, const float* wpack, float
 bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T);
 int wn_iaf_c_set_attrs(wn_handle* h);
 size_t wn_iaf_c_floats(int R, int64_t T);
-void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, float* C, int64_t c_bstride,
-                   int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st);
+void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off, const unsigned* order, int n_nat,
+                   float* C, int64_t c_bstride, int64_t TE, int c0, int R, int B, int64_t T, int num_cu, hipStream_t st);
 void wn_iaf_c_layer(const float* lin, float* lout, const float* C, int64_t c_bstride, const float* wpack, int64_t RS,
                     int d, int B, int64_t T, int num_cu, hipStream_t st, unsigned* status);
 bool wn_iaf_c_last_ok();
@@ -199,6 +216,13 @@ void wn_iaf_c_layer_head(const float* lin, const float* C, const float* Ch, int6
                          const float* wpack_head, float* x, float* Mt, float* St, int64_t RS, int XR, int d, int first,
                          int B, int64_t T, int num_cu, hipStream_t st, unsigned* status);
 bool wn_iaf_c_pair_ok(int da, int db);
+// ---- layer groups resident in LDS (wn_iaf_g.hip) ----
+bool wn_iaf_g_plan(const std::vector<int>& dilations, std::vector<WnGroup>& out);
+int wn_iaf_g_set_attrs(wn_handle* h);
+void wn_iaf_g_run(const wn_handle* h, const WnGroup& g, const IafLayerPack* layers, const float* Cg, size_t rb_floats,
+                  int64_t c_bstride, const float* lin, float* lout, int64_t RS, int out_dec, int B, int64_t T,
+                  const float* x, int XR, const float* wstart, bool last, const float* whead, float* xio, float* Mt,
+                  float* St, int first_flow, unsigned* status, hipStream_t st);
 void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
                    const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,
                    const float* x, int XR, const float* wstart, unsigned* status);

@@ -28,6 +28,6 @@ for sub in ("sq", "fetch", "write", "inst", "tcc"):
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
         cnt[(k, row["Counter_Name"])] += 1
     for k in agg:
-        if "iaf_layer" in k or "deconv_mfma" in k or "iaf_head" in k or "iaf_cond" in k or "iaf_pair" in k:
+        if "iaf_layer" in k or "deconv_mfma" in k or "iaf_head" in k or "iaf_cond" in k or "iaf_pair" in k or "iaf_group" in k:
             print(sub, k, {c: round(v / cnt[(k, c)], 1) for c, v in agg[k].items()}, "dispatches", max(cnt[(k, c)] for c in agg[k]))
 PY
