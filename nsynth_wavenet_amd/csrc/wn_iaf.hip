@@ -449,7 +449,7 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F, int form) {
     L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
     L.lA = carve((size_t)B * IAF_W * L.RS);
     L.lB = carve((size_t)B * IAF_W * L.RS);
-    L.x = carve((size_t)B * L.XR);
+    L.x = carve((size_t)2 * B * L.XR);      // flow input and, for flows that are ONE layer group, a second copy (wn_iaf_g.hip)
     L.x0 = carve((size_t)B * L.T);
     L.M = carve((size_t)B * L.T);
     L.S = carve((size_t)B * L.T);
@@ -606,6 +606,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     float* lA = reinterpret_cast<float*>(base + L.lA);
     float* lB = reinterpret_cast<float*>(base + L.lB);
     float* x = reinterpret_cast<float*>(base + L.x);
+    float* const xbuf0 = x;
     float* x0g = reinterpret_cast<float*>(base + L.x0);
     float* Mt = reinterpret_cast<float*>(base + L.M);
     float* St = reinterpret_cast<float*>(base + L.S);
@@ -646,7 +647,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
         const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
         dim3 g((pad + 255) / 256, rows, 3);
-        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, B, status,
+        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, 2 * B, status,
                            use_groups ? 64 + (int)(L.T / 32) : 0);
     }
     // noise
@@ -704,10 +705,14 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
             for (size_t gi = 0; gi < fp.groups.size(); ++gi) {
                 const WnGroup& g = fp.groups[gi];
                 const bool lastg = gi + 1 == fp.groups.size();
+                // a flow that is ONE group reads x (start conv, with its halo) and writes x (head) in the same launch:
+                // the new x goes to the other copy, which becomes the flow input from then on
+                float* xnew = (gi == 0 && lastg) ? (x == xbuf0 ? xbuf0 + (size_t)B * L.XR : xbuf0) : x;
                 wn_iaf_g_run(h, g, fp.layers.data(), Cf + (size_t)g.begin * rb_floats, rb_floats, L.c_bstride, gin, gout,
                              L.RS, lastg ? 0 : fp.groups[gi + 1].kind, B, L.T, gi == 0 ? x : nullptr, L.XR,
-                             h->d_blob + fp.start_off, lastg, h->d_blob + fp.head_off_h, x, Mt, St, k == 0 ? 1 : 0, status,
-                             st);
+                             h->d_blob + fp.start_off, lastg, h->d_blob + fp.head_off_h, x, xnew, Mt, St, k == 0 ? 1 : 0,
+                             status, st);
+                x = xnew;
                 std::swap(gin, gout);
             }
             if (h->prof_on) {

@@ -77,7 +77,9 @@ struct GArgs {
     // LAST: the group closes a flow, the flow head runs on its output
     const float* Ch;
     const unsigned* whead;
-    float* xio;
+    const float* xin;       // flow input ...
+    float* xout;            // ... and output x <- x * s + mean: the same array, except when the flow is ONE group (FIRST
+                            // and LAST in one launch): neighbouring segments still read x[t-3 .. t-1] for their start conv
     float* Mt;
     float* St;
     int64_t T;
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     const int64_t t = time_of(i);
                     const float mean = pm + bmean;
                     const float sc = fminf(fmaxf(softplus_tf(ps + bscale), EXP_M9), EXP_7);   // :105-114
-                    float* xp = A.xio + (size_t)b * A.XR + IAF_XP + t;
-                    *xp = *xp * sc + mean;                                                    // :277
+                    const size_t xo = (size_t)b * A.XR + IAF_XP + t;
+                    A.xout[xo] = A.xin[xo] * sc + mean;                                       // :277
                     float* mp = A.Mt + (size_t)b * A.T + t;
                     float* sp = A.St + (size_t)b * A.T + t;
                     if (A.first_flow) { *mp = mean; *sp = sc; }
@@ -403,8 +405,8 @@ bool wn_iaf_g_plan(const std::vector<int>& dil, std::vector<WnGroup>& out) {
 // follow at rb_floats); the head's row block (last == true) follows the last layer's.
 void wn_iaf_g_run(const wn_handle* h, const WnGroup& g, const IafLayerPack* layers, const float* Cg, size_t rb_floats,
                   int64_t c_bstride, const float* lin, float* lout, int64_t RS, int out_dec, int B, int64_t T,
-                  const float* x, int XR, const float* wstart, bool last, const float* whead, float* xio, float* Mt,
-                  float* St, int first_flow, unsigned* status, hipStream_t st) {
+                  const float* x, int XR, const float* wstart, bool last, const float* whead, const float* xin,
+                  float* xout, float* Mt, float* St, int first_flow, unsigned* status, hipStream_t st) {
     GArgs A{};
     A.lin = reinterpret_cast<const unsigned*>(lin);
     A.lout = reinterpret_cast<unsigned*>(lout);
@@ -436,7 +438,8 @@ void wn_iaf_g_run(const wn_handle* h, const WnGroup& g, const IafLayerPack* laye
     A.wstart = wstart;
     A.Ch = Cg + (size_t)A.nl * rb_floats;
     A.whead = reinterpret_cast<const unsigned*>(whead);
-    A.xio = xio;
+    A.xin = xin;
+    A.xout = xout;
     A.Mt = Mt;
     A.St = St;
     A.T = T;

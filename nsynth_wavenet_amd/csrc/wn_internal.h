@@ -221,8 +221,8 @@ bool wn_iaf_g_plan(const std::vector<int>& dilations, std::vector<WnGroup>& out)
 int wn_iaf_g_set_attrs(wn_handle* h);
 void wn_iaf_g_run(const wn_handle* h, const WnGroup& g, const IafLayerPack* layers, const float* Cg, size_t rb_floats,
                   int64_t c_bstride, const float* lin, float* lout, int64_t RS, int out_dec, int B, int64_t T,
-                  const float* x, int XR, const float* wstart, bool last, const float* whead, float* xio, float* Mt,
-                  float* St, int first_flow, unsigned* status, hipStream_t st);
+                  const float* x, int XR, const float* wstart, bool last, const float* whead, const float* xin,
+                  float* xout, float* Mt, float* St, int first_flow, unsigned* status, hipStream_t st);
 void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* CB, int64_t c_bstride, const float* wA,
                    const float* wB, int64_t RS, int da, int db, int B, int64_t T, int num_cu, hipStream_t st,
                    const float* x, int XR, const float* wstart, unsigned* status);

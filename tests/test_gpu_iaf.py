@@ -573,7 +573,7 @@ def test_fp16_range_is_guarded_never_silent():
     cfgd, hp, w, mel, noise = _overflow_case(1200.0)
     ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
     assert np.isfinite(ref['x']).all() and np.abs(ref['x']).max() > 1e5        # the reference's fp32 graph is finite here
-    assert ref['scale_tot'].max() > 0.99 * np.exp(14.0)                         # e^7 reached in two flows somewhere
+    assert ref['scale_tot'].max() > 0.99 * np.exp(7.0)                          # the e^7 clip is reached (:327 caps the product)
     for prec in ('f16x3', 'f16x3-fused'):
         eng = Engine(cfgd, precision=prec).load_weights(w)
         raw = eng.iaf_generate(mel, noise, want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot'), check_range=False)
