@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libwnhip.so')
+# WN_LIB_PATH: another build of the same library (A/B measurements of kernel variants on one box); never a fallback
+LIB_PATH = os.environ.get('WN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libwnhip.so')
 
 WN_MAX_DECONV = 4
 WN_MAX_FLOWS = 8

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
-LIB_PATH = os.path.join(LIB_DIR, 'libwnhip.so')
+LIB_PATH = os.path.join(LIB_DIR, os.environ.get('WN_LIB_NAME', 'libwnhip.so'))     # WN_LIB_NAME: variant builds for A/B runs
 SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
 HEADERS = ['wn_internal.h', 'wn_codec.h', 'wn_pack_h.h', 'wn_mfma_h.h', 'wn_iaf_c.h', os.path.join(ROOT, 'include', 'wnhip.h')]
 
@@ -26,7 +26,7 @@ def find_hipcc():
     raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
 
 
-STAMP_PATH = os.path.join(LIB_DIR, 'libwnhip.sha256')
+STAMP_PATH = os.path.splitext(LIB_PATH)[0] + '.sha256'
 
 
 def _deps():
@@ -69,7 +69,7 @@ def build(force=False, verbose=True):
         os.environ.get('WN_EXTRA_FLAGS', '').split()
     procs = []
     for s in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(s)[0] + '.o')
+        obj = os.path.join(LIB_DIR, os.path.splitext(s)[0] + ('' if LIB_PATH.endswith('libwnhip.so') else '_v') + '.o')
         cmd = [hipcc] + common + (['-x', 'hip'] if s.endswith('.cpp') else []) + \
               ['-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:

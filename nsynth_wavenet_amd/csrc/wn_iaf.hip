@@ -638,8 +638,14 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     // whole call.  WN_NO_GROUPS=1: the per-layer / layer-pair launches (A/B measurements, cross-form tests).
     const char* ng = getenv("WN_NO_GROUPS");
     const bool no_groups = ng && atoi(ng) != 0;
+    // Where it pays: the group kernel is compute-bound per CU (its halo costs 28 % more matrix and VALU work, and the
+    // two do not overlap on a gfx950 SIMD, scripts/ubench/mfma_valu_overlap.hip) and wins by launching 12 times instead
+    // of 52 -- + 9 % at one utterance, +- 0 at two, - 2 ... - 4 % from four on, where the per-layer launches are full.
+    // Default: while a natural group has at most two segments per CU.  WN_GROUPS=1 forces it on at any batch.
+    const char* fg = getenv("WN_GROUPS");
+    const bool small_call = (int64_t)B * ((L.T / 16 + 19) / 20) <= 2 * (int64_t)h->num_cu;
     const bool use_groups = f16x3 && L.form == WN_COND_HOISTED && h->groups_ok && !no_groups && L.T % 512 == 0 &&
-                            4 * IAF_LP == 32 * 64 * 4;
+                            (small_call || (fg && atoi(fg) != 0));
     // zero left pads
     {
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
@@ -878,6 +884,9 @@ extern "C" int wn_iaf_range_status(wn_handle* h, const void* ws, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WN_HIP(h, hipMemcpyAsync(&flag, ws, sizeof(flag), hipMemcpyDeviceToHost, st));      // the status word leads the workspace
     WN_HIP(h, hipStreamSynchronize(st));
+    if (flag & 2u)
+        return wn_fail(h, WN_EIO, "wn_iaf_generate: a fragment slot of the layer-group kernel never became ready (LDS-DMA "
+                       "hand-off timed out); the outputs of that call are NaN.  WN_GROUP_FORM=1 selects the barrier-only form");
     if (flag)
         return wn_fail(h, WN_ERANGE, "wn_iaf_generate: an activation left the fp16 range of the split-fp16 arithmetic "
                        "(|value| >= 65504); the outputs of that call are NaN -- re-run it with "

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
 int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
     const wn_config& c = h->cfg;
     auto var = [&](const std::string& nme) -> const std::vector<float>& { return h->vars.at(nme).data; };
+    unsigned layer_id = 0;
     for (int k = 0; k < c.n_flows; ++k) {
         const std::string p = "iaf_" + std::to_string(k + 1);
         IafFlowPack& fp = h->flows[k];
@@ -424,6 +425,8 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
             tb[128] = 1.0f / sm;
             tb[129] = 1.0f / sr;
             tb[130] = tb[131] = 0.f;
+            fp.layers[i].id = ++layer_id;
+            for (int m = 0; m < 4; ++m) memcpy(&tb[132 + m], &fp.layers[i].id, 4);
         }
         {
             std::vector<float> Wo = wn_get_kernel(h, p + "/out1", "W", false);            // [64][64]

@@ -50,6 +50,7 @@ struct IafLayerPack {
     size_t off;                        // fp32 path: LAYER_FLOATS floats: P | PR | bgate | bres
     size_t off_h;                      // split-fp16 path: IAF_LAYER_H_WORDS words (wn_iaf_h.hip)
     int dilation;
+    unsigned id = 0;                   // 1-based number of the layer in the student (marker value, wn_iaf_g.hip)
 };
 struct IafFlowPack {
     size_t start_off;                  // w[3][W] | b[W]
@@ -163,7 +164,8 @@ constexpr int IAF_LAYER_FLOATS = IAF_P_FLOATS + IAF_PR_FLOATS + 64 + 64;   // 30
 constexpr int IAF_PH_FLOATS = 80 * 4 * 64;       // 20480
 constexpr int IAF_HEAD_FLOATS = IAF_PH_FLOATS + 64 * 3 + 4;                 // 20676
 
-constexpr int IAF_LAYER_H_WORDS = IAF_P_FLOATS + IAF_PR_FLOATS + 128 + 4;   // + 1/scale_main, 1/scale_res
+constexpr int IAF_LAYER_H_WORDS = IAF_P_FLOATS + IAF_PR_FLOATS + 128 + 4 + 4;   // + 1/scale_main, 1/scale_res, pad; + marker quad
+                                                                            // (the layer's id x 4: wn_iaf_g.hip's DMA-delivered 'slot ready' word)
 // precision of the IAF contractions (wn_config.precision)
 constexpr int WN_PREC_F16X3 = 0;   // split-fp16 on the fp16 MFMA (default)
 constexpr int WN_PREC_F32 = 1;     // fp32 MFMA

@@ -375,7 +375,7 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
     decimated block per residue, several utterances, the centre-crop variant, and private deconv stacks."""
     from oracle import wavenet_np as O
     rs = np.random.RandomState(78)
-    for extra, shapes in (({}, ((1, 8), (1, 35), (3, 80), (2, 391), (5, 13), (1, 400))),
+    for extra, shapes in (({}, ((1, 8), (1, 35), (3, 80), (2, 391), (5, 13), (1, 400), (6, 200))),
                           ({'use_share_deconv': False, 'num_iaf_layers': [10, 20]}, ((2, 30), (1, 77))),
                           ({'num_iaf_layers': [5, 12, 7]}, ((2, 21), (1, 130)))):
         cfgd = dict(load_json('parallel_wavenet.json'), **extra)
@@ -387,8 +387,10 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
             mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
             noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
             monkeypatch.delenv('WN_NO_GROUPS', raising=False)
+            monkeypatch.setenv('WN_GROUPS', '1')          # at any batch size (the default keeps it to small calls)
             a = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
             a2 = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
+            monkeypatch.delenv('WN_GROUPS', raising=False)
             monkeypatch.setenv('WN_NO_GROUPS', '1')
             b = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
             for k in a:
