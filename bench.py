@@ -45,10 +45,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4
 PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 PROFILE_ROUND = 'r03'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
-DOMINANT_KERNEL = 'iaf_layer_c_kernel'
+DOMINANT_KERNEL = 'iaf_group_kernel'    # layer groups at one / two utterances; 'iaf_layer_c_kernel' when every layer is a launch
+GROUP_LAYERS = 5                       # residual layers per launch of the group kernel (one half of a dilation cycle)
+# one 16-sample block of one residual layer on a gfx950 SIMD: 84 MFMAs x 16 cycles + the epilogue's 163 VALU x 4 + 32
+# transcendental x 16 cycles -- and the two do NOT overlap on this part (scripts/ubench/mfma_valu_overlap.hip)
+BLOCK_LAYER_PIPE_CYCLES = 84 * 16 + 163 * 4 + 32 * 16
 
 
-def pmc_traffic(B, F, precision='f16x3', hoisted=False):
+def pmc_traffic(B, F, precision='f16x3', hoisted=False, kernel=None):
     """HBM bytes per launch of the dominant layer kernel from the committed rocprofv3 PMC passes
     (profiles/r0*_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
     PMC counters cannot be collected from inside this process, so this is the value of the profiled
@@ -58,7 +62,8 @@ def pmc_traffic(B, F, precision='f16x3', hoisted=False):
     if precision == 'f32':
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
     elif precision in ('f16x3', 'f16x3-hoisted') and hoisted:
-        names, kernel = [PROFILE_ROUND + '_pmc_summary_f16x3.json', PROFILE_ROUND + '_pmc_summary_f16x3_batch8.json'], DOMINANT_KERNEL
+        names = [PROFILE_ROUND + '_pmc_summary_f16x3.json', PROFILE_ROUND + '_pmc_summary_f16x3_batch8.json']
+        kernel = kernel or DOMINANT_KERNEL
     elif precision in ('f16x3', 'f16x3-fused') and not hoisted:
         names, kernel = [PROFILE_ROUND + '_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
     else:
@@ -198,7 +203,38 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
     achieved_tf = flops_per_launch / avg_layer_s / 1e12
     achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
     hoisted = eng.iaf_cond_hoisted(B, F)
-    if hoisted:
+    kernel_key = None
+    if hoisted and eng.iaf_layer_groups(B, F):
+        # Layer groups: one launch = GROUP_LAYERS residual layers of every sample, the residual stream in LDS; the event
+        # pairs bracket every group launch of the call.  `achieved` counts the bytes such a launch has to move in this
+        # design (read l 256 B, GROUP_LAYERS hoisted terms of 256 B, write l 256 B per sample; halo re-reads excluded);
+        # SURVEY 8(d)'s layer-granular model (1536 B per sample and layer) is given beside it.  The launch is NOT
+        # HBM-bound: a CU spends it in the matrix pipe and the VALU, which do not overlap on gfx950 -- pipe_view.
+        nl = GROUP_LAYERS
+        bytes_per_launch = (256 + 256 * nl + 256) * B * T
+        flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * nl * B * T      # without the hoisted 1x1s (the GEMM's)
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        kernel_key = 'iaf_group_kernel'
+        clock_hz = 2.05e9
+        pipe_floor_s = (B * T / 16) * nl * BLOCK_LAYER_PIPE_CYCLES / 1024 / clock_hz
+        roof = {'kernel': 'iaf_group_kernel (wn_iaf_g.hip: {} residual layers per launch on hoisted conditioning, l resident '
+                          'in LDS, causal halo recomputed; natural and decimated groups alternate)'.format(nl),
+                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'layers_per_launch': nl,
+                'survey_8d_view': {'bytes_per_launch': LAYER_BYTES_PER_SAMPLE * nl * B * T,
+                                   'GBps': LAYER_BYTES_PER_SAMPLE * nl * B * T / avg_layer_s / 1e9,
+                                   'frac': LAYER_BYTES_PER_SAMPLE * nl * B * T / avg_layer_s / 1e9 / PEAK_HBM_GBPS,
+                                   'note': '1536 B per sample and layer (each layer reads l and enc, writes l): the traffic '
+                                           'this launch replaces'},
+                'pipe_view': {'floor_us': pipe_floor_s * 1e6, 'frac_of_floor': pipe_floor_s / avg_layer_s,
+                              'executed_fp16_TFLOPs': 3 * flops_per_launch / avg_layer_s / 1e12,
+                              'note': 'per 16-sample block and layer a SIMD needs 84 MFMAs (1344 cycles) + the gate / split '
+                                      'epilogue (1164 cycles of VALU and transcendentals), serialised; floor at 2.05 GHz on '
+                                      '1024 SIMDs without halo'}}
+    elif hoisted:
+        kernel_key = 'iaf_layer_c_kernel'
+        flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * B * T
         # conditioning 1x1s hoisted into one GEMM per deconv stack (the default): the layer
         # kernel streams l in/out and the projected term, 768 B/sample; the event pairs bracket the
         # single-layer launches only (36 of the 60 layers; the other 24 run two per launch)
@@ -223,7 +259,7 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
                 'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                 'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
-    roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted),
+    roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted, kernel_key),
                  'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass of this command on these kernel sources, '
                                  'profiles/; null when no such pass is committed)',
                  'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,

@@ -633,19 +633,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         h->iaf_attrs_set = true;
     }
 
-    // The layer-group kernel (wn_iaf_g.hip) runs the hoisted form whenever every flow has a group plan and the
-    // decimated view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the
-    // whole call.  WN_NO_GROUPS=1: the per-layer / layer-pair launches (A/B measurements, cross-form tests).
-    const char* ng = getenv("WN_NO_GROUPS");
-    const bool no_groups = ng && atoi(ng) != 0;
-    // Where it pays: the group kernel is compute-bound per CU (its halo costs 28 % more matrix and VALU work, and the
-    // two do not overlap on a gfx950 SIMD, scripts/ubench/mfma_valu_overlap.hip) and wins by launching 12 times instead
-    // of 52 -- + 9 % at one utterance, +- 0 at two, - 2 ... - 4 % from four on, where the per-layer launches are full.
-    // Default: while a natural group has at most two segments per CU.  WN_GROUPS=1 forces it on at any batch.
-    const char* fg = getenv("WN_GROUPS");
-    const bool small_call = (int64_t)B * ((L.T / 16 + 19) / 20) <= 2 * (int64_t)h->num_cu;
-    const bool use_groups = f16x3 && L.form == WN_COND_HOISTED && h->groups_ok && !no_groups && L.T % 512 == 0 &&
-                            (small_call || (fg && atoi(fg) != 0));
+    const bool use_groups = f16x3 && wn_iaf_use_groups(h, B, L.T, L.form);
     // zero left pads
     {
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
@@ -864,6 +852,28 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
         for (const IafFlowPack& fp : h->flows) rows = std::max(rows, (int)fp.layers.size() + 1);
     }
     return (double)B * (double)T * 256.0 * rows <= h->hoist_limit_bytes;
+}
+
+// The layer-group kernel (wn_iaf_g.hip) runs the hoisted form whenever every flow has a group plan and the decimated
+// view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the whole call.
+// Where it pays: the group kernel is compute-bound per CU (its halo costs 28 % more matrix and VALU work, and the two
+// do not overlap on a gfx950 SIMD, scripts/ubench/mfma_valu_overlap.hip) and wins by launching 12 times instead of
+// 52 -- + 9 % at one utterance, +- 0 at two, - 2 ... - 4 % from four on, where the per-layer launches are full.
+// Default: while a natural group has at most two segments per CU.  WN_GROUPS=1 forces it on at any batch size,
+// WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
+bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
+    if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
+    const char* ng = getenv("WN_NO_GROUPS");
+    if (ng && atoi(ng) != 0) return false;
+    const char* fg = getenv("WN_GROUPS");
+    if (fg && atoi(fg) != 0) return true;
+    return (int64_t)B * ((T / 16 + 19) / 20) <= 2 * (int64_t)h->num_cu;
+}
+
+extern "C" int wn_iaf_layer_groups(const wn_handle* h, int B, int F) {
+    if (!h || h->cfg.kind != WN_KIND_STUDENT || B < 1 || F < 1 || h->cfg.precision != WN_PREC_F16X3) return 0;
+    const int64_t T = wn_iaf_length(h, F);
+    return wn_iaf_use_groups(h, B, T, wn_iaf_form(h, B, T, WN_FORM_DEFAULT)) ? 1 : 0;
 }
 
 extern "C" int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F) {

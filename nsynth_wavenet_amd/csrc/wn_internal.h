@@ -231,6 +231,7 @@ void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* 
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
                    float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
 int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form);   // WN_COND_FUSED / _HOISTED for this call (form: WN_FORM_*)
+bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int cond_form);   // layer-group kernel for this call?
 int wn_form_precision(const wn_handle* h, int form);              // WN_PREC_* a call of this form computes in
 std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, const char* name, bool deconv);
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F, int form = WN_FORM_DEFAULT);

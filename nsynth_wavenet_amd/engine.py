@@ -221,6 +221,10 @@ class Engine(object):
         """True when iaf_generate(batch, num_frames) runs the hoisted-conditioning kernels."""
         return bool(self.lib.wn_iaf_cond_hoisted(self._h, int(batch), int(num_frames)))
 
+    def iaf_layer_groups(self, batch, num_frames):
+        """True when iaf_generate(batch, num_frames) runs the residual layers in LDS-resident layer groups."""
+        return bool(self.lib.wn_iaf_layer_groups(self._h, int(batch), int(num_frames)))
+
     # ---- measurement aid (bench.py) ----
     def profile_begin(self):
         self._check(self.lib.wn_profile_begin(self._h))

@@ -1,7 +1,7 @@
 """Build a profiles/rNN_pmc_summary_*.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
     python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json [batch_per_gpu] [bench args]
 Kernels are keyed by their base name; variants that do different work per launch keep their own key
-("iaf_layer_h_kernel<first>": start conv fused in; "iaf_layer_c_kernel<head>": flow head in the epilogue;
+("iaf_layer_h_kernel<first>": start conv fused in; "iaf_layer_c_kernel<head>": flow head in the epilogue; "iaf_group_kernel<first>" / "<head>": layer groups that open / close a flow;
 "iaf_pair_c_kernel<...>": per template arguments)."""
 import collections, csv, glob, json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,6 +32,10 @@ def key_of(name):
     if base == 'iaf_layer_c_kernel':      # template <HN, LAST, W2, DMA, NOPF>: only LAST changes the work per launch
         a = [x.strip() for x in targs.strip('<>').split(',')]
         return base + '<head>' if len(a) > 1 and a[1] == 'true' else base
+    if base == 'iaf_group_kernel':       # template <FIRST, LAST>: the start conv instead of reading l / the head instead of writing l
+        a = [x.strip() for x in targs.strip('<>').split(',')]
+        tag = ','.join(t for t, on in (('first', a[0] == 'true'), ('head', len(a) > 1 and a[1] == 'true')) if on)
+        return base + ('<' + tag + '>' if tag else '')
     if base == 'iaf_pair_c_kernel':
         return base + targs.replace(' ', '')
     if base in ('deconv_mfma_h_kernel', 'deconv_mfma_hs_kernel'):
