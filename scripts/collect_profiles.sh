@@ -6,12 +6,15 @@ cd "$(dirname "$0")/.."
 G=gpurun_out
 cp $G/bench_f16x3.json profiles/${R}_bench_f16x3.json
 cp $G/bench_f16x3_b8.json profiles/${R}_bench_f16x3_batch8.json
+cp $G/bench_f16x3_driver_protocol.json profiles/${R}_bench_f16x3_driver_protocol.json
+cp $G/bench_f16x3_per_layer.json profiles/${R}_bench_f16x3_per_layer_launches.json
 cp $G/bench_f16x3-fused.json profiles/${R}_bench_f16x3_fused.json
 cp $G/bench_f32.json profiles/${R}_bench_fp32.json
 for b in 1 8 64; do cp $G/bench_ar_b$b.json profiles/${R}_bench_ar_batch$b.json; done
 cp $G/bench_teacher.json profiles/${R}_bench_teacher_forward.json
 cp $G/fin1/fin1_kernel_stats.csv profiles/${R}_kernel_stats_f16x3.csv
 cp $G/finf/finf_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_fused.csv
+cp $G/finl/finl_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_per_layer_launches.csv
 cp $G/fin8/fin8_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_batch8.csv
 python scripts/pmc_summary.py $G/pmc_fin profiles/${R}_pmc_summary_f16x3.json 1 "--no-extras"
 python scripts/pmc_summary.py $G/pmc_fused profiles/${R}_pmc_summary_f16x3_fused.json 1 "--no-extras --precision f16x3-fused"

@@ -2,6 +2,8 @@
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
 timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
+timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_f16x3_driver_protocol.json
+WN_NO_GROUPS=1 timeout 300 python bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 > gpurun_out/bench_f16x3_per_layer.json
 for p in f16x3-fused f32; do
   timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 5 --precision $p 2>&1 | tail -1 > gpurun_out/bench_$p.json
 done
@@ -14,6 +16,7 @@ bash scripts/pmc_layer.sh b8 "--no-extras --batch-per-gpu 8" > gpurun_out/pmc_b8
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin1 -o fin1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/fin1.log 2>&1
+WN_NO_GROUPS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/finl -o finl -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/finl.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/finf -o finf -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --precision f16x3-fused > $R/gpurun_out/finf.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
 cd $R; for f in gpurun_out/bench_*.json; do python -c "
