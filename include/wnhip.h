@@ -125,7 +125,10 @@ typedef struct wn_handle wn_handle;
 int wn_abi_version(void);
 
 /* Build an empty engine for one model on the current HIP device.
- * Replaces graph construction (parallelgen.py:11-19, fastgen.py:61-66,118-125). */
+ * Replaces graph construction (parallelgen.py:11-19, fastgen.py:61-66,118-125).
+ * Students of the shipped shape (width 64, deconv_width 256, num_stages >= 7) run on the MFMA kernels; any other even
+ * width <= 1024 / deconv_width % 64 == 0 / num_stages >= 3 on generic fp32 kernels (same results, much slower).
+ * Teachers need 3 * width + deconv_width <= 2048. */
 int wn_create(const wn_config* cfg_host, wn_handle** out);
 
 /* Provide one variable under its TensorFlow name WITHOUT the

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, os.environ.get('WN_LIB_NAME', 'libwnhip.so'))     # WN_LIB_NAME: variant builds for A/B runs
-SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
+SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_x.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
 HEADERS = ['wn_internal.h', 'wn_codec.h', 'wn_pack_h.h', 'wn_mfma_h.h', 'wn_iaf_c.h', os.path.join(ROOT, 'include', 'wnhip.h')]
 
 

@@ -104,14 +104,17 @@ static int validate(const wn_config& c) {
     if (c.cond_mode < WN_COND_AUTO || c.cond_mode > WN_COND_HOISTED)
         return wn_fail(nullptr, WN_EINVAL, "config: unknown conditioning mode %d (0 default, 1 fused, 2 hoisted)", c.cond_mode);
     if (c.kind == WN_KIND_STUDENT) {
-        if (c.num_stages < 7)
-            return wn_fail(nullptr, WN_EINVAL, "config: the IAF kernels tile time in 64-sample blocks and need "
-                           "num_stages >= 7 (output length is a multiple of 2^(num_stages-1)), got %d", c.num_stages);
-        if (c.width != IAF_W || c.gate_width != IAF_W || c.deconv_width != IAF_CD)
-            return wn_fail(nullptr, WN_EINVAL,
-                           "config: the IAF kernels are specialised for width 64 / deconv_width 256 "
-                           "(every shipped parallel_wavenet*.json); got width %d gate %d deconv %d",
-                           c.width, c.gate_width, c.deconv_width);
+        // width 64 / deconv_width 256 / num_stages >= 7 (every shipped parallel_wavenet*.json) run on the MFMA kernels;
+        // any other shape on the generic fp32 kernels of wn_iaf_x.hip (same results, much slower)
+        if (c.gate_width != c.width)
+            return wn_fail(nullptr, WN_EINVAL, "config: student gate_width must equal width (parallel_wavenet.py:209), "
+                           "got width %d gate %d", c.width, c.gate_width);
+        if (c.num_stages < 3)
+            return wn_fail(nullptr, WN_EINVAL, "config: student num_stages must be >= 3 (the output length is a multiple of "
+                           "2^(num_stages-1) and the noise / quantiser kernels move four samples at a time), got %d", c.num_stages);
+        if (c.width < 2 || (c.width & 1) || c.width > 1024 || c.deconv_width > 2048)
+            return wn_fail(nullptr, WN_EINVAL, "config: student width must be even and <= 1024, deconv_width <= 2048; "
+                           "got width %d deconv %d", c.width, c.deconv_width);
         if (c.n_flows < 1 || c.n_flows > WN_MAX_FLOWS)
             return wn_fail(nullptr, WN_EINVAL, "config: num_iaf_layers needs 1..%d flows", WN_MAX_FLOWS);
         if (c.loss_type != WN_LOSS_LOGISTIC && c.loss_type != WN_LOSS_GAUSS)
@@ -177,6 +180,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     }
     h->frame_shift = 1;
     for (int j = 0; j < cfg->n_deconv; ++j) h->frame_shift *= cfg->deconv_stride[j];
+    h->generic_student = cfg->kind == WN_KIND_STUDENT &&
+                         (cfg->width != IAF_W || cfg->deconv_width != IAF_CD || cfg->num_stages < 7);
 
     const wn_config& c = h->cfg;
     if (c.kind == WN_KIND_STUDENT) {
@@ -258,10 +263,10 @@ extern "C" int wn_finalize(wn_handle* h) {
     std::vector<float> blob;
     int rc = wn_pack_deconv(h, blob);
     if (rc) return rc;
-    rc = h->cfg.kind == WN_KIND_STUDENT ? wn_pack_iaf(h, blob) : wn_pack_ar(h, blob);
+    rc = h->cfg.kind != WN_KIND_STUDENT ? wn_pack_ar(h, blob) : h->generic_student ? wn_pack_iaf_x(h, blob) : wn_pack_iaf(h, blob);
     if (rc) return rc;
     if (h->cfg.kind == WN_KIND_STUDENT) {
-        rc = wn_pack_iaf_h(h, blob);
+        if (!h->generic_student) rc = wn_pack_iaf_h(h, blob);
         if (rc) return rc;
     } else {
         rc = wn_pack_teacher(h, blob);

@@ -446,6 +446,23 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F, int form) {
     auto carve = [&](size_t floats) { size_t r = o; o += align_up(floats * sizeof(float), 256); return r; };
     L.form = wn_iaf_form(h, B, L.T, form);
     L.status = carve(64);                                  // range-guard word: first bytes of the workspace
+    if (h->generic_student) {                              // fp32 rows of the model's own widths (wn_iaf_x.hip)
+        const size_t W = h->cfg.width, Cd = h->cfg.deconv_width;
+        L.form = WN_COND_FUSED;
+        L.enc = carve((size_t)B * Cd * L.TE + 64);
+        L.lA = carve((size_t)B * W * L.RS);
+        L.lB = carve((size_t)B * W * L.RS);
+        L.x = carve((size_t)2 * B * L.XR);
+        L.x0 = carve((size_t)B * L.T);
+        L.M = carve((size_t)B * L.T);
+        L.S = carve((size_t)B * L.T);
+        L.c_bstride = 0;
+        L.C = o;
+        L.scratch = o;
+        o += wn_deconv_scratch_bytes(h, B, F);
+        L.total = o;
+        return L;
+    }
     L.enc = carve((size_t)B * IAF_CD * L.TE + 64);
     L.lA = carve((size_t)B * IAF_W * L.RS);
     L.lB = carve((size_t)B * IAF_W * L.RS);
@@ -574,6 +591,66 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
+// A student whose widths the MFMA kernels are not specialised for: the same call on the generic fp32 kernels of
+// wn_iaf_x.hip (fp32 upsampler GEMM, one launch per start conv / layer / head, fp32 rows, no fp16 anywhere).
+static int iaf_generate_generic(wn_handle* h, const IafLayout& L, const float* mel, int B, int F, const float* noise,
+                                uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot, float* scale_tot,
+                                float* rand_out, char* base, hipStream_t st) {
+    const wn_config& c = h->cfg;
+    float* enc = reinterpret_cast<float*>(base + L.enc);
+    float* lA = reinterpret_cast<float*>(base + L.lA);
+    float* lB = reinterpret_cast<float*>(base + L.lB);
+    float* x = reinterpret_cast<float*>(base + L.x);
+    float* x0g = reinterpret_cast<float*>(base + L.x0);
+    float* Mt = reinterpret_cast<float*>(base + L.M);
+    float* St = reinterpret_cast<float*>(base + L.S);
+    unsigned* status = reinterpret_cast<unsigned*>(base + L.status);
+    void* scratch = base + L.scratch;
+    if (!h->iaf_attrs_set) {
+        if (int rc = wn_iaf_x_set_attrs(h)) return rc;
+        h->iaf_attrs_set = true;
+    }
+    {
+        const int rows = B * c.width;
+        dim3 g((IAF_LP + 255) / 256, rows, 3);
+        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, L.RS, IAF_LP, rows, x, (int64_t)L.XR, IAF_XP, 2 * B,
+                           status, 0);
+    }
+    const float* x0 = noise;
+    {
+        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
+        if (noise) {
+            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
+        } else {
+            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
+                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
+            x0 = x0g;
+        }
+    }
+    if (c.share_deconv)
+        if (int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, false, nullptr, WN_PREC_F32)) return rc;
+    for (int k = 0; k < c.n_flows; ++k) {
+        const IafFlowX& fx = h->flows_x[k];
+        if (!c.share_deconv)
+            if (int rc = wn_run_deconv(h, fx.deconv_stack, mel, B, F, enc, L.TE, scratch, st, false, nullptr, WN_PREC_F32)) return rc;
+        wn_iaf_x_start(h, fx, x, lA, L.T, L.XR, L.RS, B, st);
+        float* lin = lA;
+        float* lout = lB;
+        for (const IafLayerX& lx : fx.layers) {
+            wn_iaf_x_layer(h, lx, lin, lout, enc, L.RS, L.TE, L.c0, B, L.T, st);
+            std::swap(lin, lout);
+        }
+        wn_iaf_x_head(h, fx, lin, enc, x, Mt, St, L.RS, L.TE, L.c0, L.XR, L.T, k == 0 ? 1 : 0, B, st);
+    }
+    const int64_t nn = (int64_t)B * L.T;
+    const int Q = c.use_mu_law ? 256 : 65536;
+    hipLaunchKernelGGL(iaf_final_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, x0, Mt, St, nn, Q, c.use_mu_law,
+                       wav, idx, x_raw, mean_tot, scale_tot, status);
+    if (rand_out && rand_out != x0) WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
 extern "C" int wn_iaf_generate(wn_handle* h, const float* mel, int B, int F, const float* noise,
                                uint64_t seed, float* wav, int32_t* idx, float* x_raw, float* mean_tot,
                                float* scale_tot, float* rand_out, void* ws, size_t ws_bytes, void* stream) {
@@ -615,6 +692,8 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     void* scratch = base + L.scratch;
     const wn_config& c = h->cfg;
 
+    if (h->generic_student)
+        return iaf_generate_generic(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
     const int prec = wn_form_precision(h, form);
     const bool f16x3 = prec == WN_PREC_F16X3;
     if (!h->iaf_attrs_set) {       // per handle: function attributes belong to the handle's device

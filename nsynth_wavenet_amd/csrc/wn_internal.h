@@ -62,6 +62,19 @@ struct IafFlowPack {
     int rb_base;                       // first row block of this flow in the hoisted-conditioning table
 };
 
+// Student of a shape the MFMA kernels are not specialised for (wn_iaf_x.hip): plain fp32 tensors in TF layout
+struct IafLayerX {
+    size_t wd, wc, wr, bd, bc, br;     // [3][W][W], [Cd][W], [W/2][W], biases
+    int dilation;
+};
+struct IafFlowX {
+    size_t start;                      // w[3][W] | b[W]
+    std::vector<IafLayerX> layers;
+    size_t wo, wco, bo, bco, wm, ws;   // out1 [W][W], mel_cond_out1 [Cd][W], biases, out2_mean / out2_scale [W]
+    float bmean, bscale;
+    int deconv_stack;
+};
+
 // Teacher (wn_ar.hip): plain [out][in] row-major matrices
 struct ArLayerPack {
     size_t wd_off;    // [gate][3*width + deconv_width]   (taps t-2d, t-d, t, cond)
@@ -113,6 +126,8 @@ struct wn_handle {
     size_t blob_floats = 0;
     std::vector<DeconvStackPack> stacks;
     std::vector<IafFlowPack> flows;
+    std::vector<IafFlowX> flows_x;            // generic-width student (wn_iaf_x.hip) instead of `flows`
+    bool generic_student = false;             // width / deconv_width / num_stages outside the MFMA kernels' shape
     ArPack ar;
     TeacherPack teacher;
     // hoisted conditioning (wn_iaf_c.hip): word offsets of the 8-K-step cond fragment arrays of
@@ -198,6 +213,15 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
                   unsigned* status = nullptr, int prec = -1);
 
 int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
+// ---- generic-width student (wn_iaf_x.hip) ----
+int wn_pack_iaf_x(wn_handle* h, std::vector<float>& blob);
+int wn_iaf_x_set_attrs(wn_handle* h);
+void wn_iaf_x_start(const wn_handle* h, const IafFlowX& fx, const float* x, float* l, int64_t T, int XR, int64_t RS, int B,
+                    hipStream_t st);
+void wn_iaf_x_layer(const wn_handle* h, const IafLayerX& lx, const float* lin, float* lout, const float* enc, int64_t RS,
+                    int64_t TE, int c0, int B, int64_t T, hipStream_t st);
+void wn_iaf_x_head(const wn_handle* h, const IafFlowX& fx, const float* lin, const float* enc, float* x, float* Mt,
+                   float* St, int64_t RS, int64_t TE, int c0, int XR, int64_t T, int first, int B, hipStream_t st);
 int wn_iaf_h_set_attrs(wn_handle* h);
 void wn_iaf_h_start(const float* x, const float* wb, float* l, int64_t T, int XR, int64_t RS, int B, hipStream_t st,
                     unsigned* status);

@@ -605,3 +605,49 @@ def test_fp16_range_is_guarded_never_silent():
     out = eng.iaf_generate(mel, noise, want=('x',))
     assert eng.range_fallbacks == 0 and np.abs(_np(out['x']) - ref['x']).max() <= 2e-5 * np.abs(ref['x']).max()
     eng.close()
+
+
+@pytest.mark.parametrize('patch', [
+    {'width': 32, 'deconv_width': 128, 'num_stages': 5, 'num_iaf_layers': [6, 7]},
+    {'width': 128, 'deconv_width': 256, 'num_iaf_layers': [10, 3], 'use_share_deconv': False},
+    {'width': 48, 'deconv_width': 64, 'num_stages': 4, 'num_iaf_layers': [5], 'loss_type': 'gauss',
+     'deconv_config': [[8, 2], [12, 4]], 'use_mu_law': True},
+])
+def test_student_shapes_outside_the_mfma_kernels(patch):
+    """masked.conv1d takes any num_filters (masked.py:160-232) and ParallelWavenet any width / deconv_config /
+    num_stages (parallel_wavenet.py:124-141,200-287).  The MFMA kernels cover the shipped shape (width 64, deconv
+    width 256, ten stages); every other student runs on the generic fp32 kernels (csrc/wn_iaf_x.hip) behind the same
+    C ABI and is held to the same float64 oracle: narrow and wide residual stacks, five- and four-stage dilation
+    cycles (output length a multiple of 16 / 8, centre crop), private upsamplers, a Gaussian mu-law student with its
+    own deconv_config."""
+    from oracle import wavenet_np as O
+    cfgd = dict(load_json('parallel_wavenet.json'), **patch)
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=99, init='unit')
+    eng = _engine(cfgd, w)
+    shift = int(np.prod([s for _, s in cfgd['deconv_config']]))
+    for B, F in ((1, 3), (3, 17)):
+        T = O.iaf_length(F, hp)
+        assert T > 0 and T % (2 ** (cfgd['num_stages'] - 1)) == 0 and T <= F * shift
+        mel = np.random.RandomState(B).uniform(0, 1, [B, F, 80]).astype(np.float32)
+        if cfgd.get('loss_type') == 'gauss':
+            noise = np.random.RandomState(7).standard_normal([B, T]).astype(np.float32)
+        else:
+            noise = O.logistic_from_uniform(np.random.RandomState(7).uniform(1e-5, 1 - 1e-5, [B, T]), np.float32)
+        ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+        out = eng.iaf_generate(mel, noise, want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot'))
+        scale = max(1.0, float(np.abs(ref['x']).max()))
+        assert np.abs(_np(out['x']) - ref['x']).max() <= 2e-5 * scale
+        assert np.abs(_np(out['mean_tot']) - ref['mean_tot']).max() <= 2e-5 * max(1.0, np.abs(ref['mean_tot']).max())
+        assert np.abs(_np(out['scale_tot']) - ref['scale_tot']).max() <= 2e-5 * max(1.0, np.abs(ref['scale_tot']).max())
+        Q = 256 if cfgd['use_mu_law'] else 65536
+        wav_ref, idx_ref = O.clip_quant_scale(ref['x'], Q, cfgd['use_mu_law'], np.float64)
+        assert np.abs(_np(out['idx']).astype(np.int64) - idx_ref).max() <= 1
+        # the index is exact for the engine's own float signal
+        _, idx_own = O.clip_quant_scale(_np(out['x']), Q, cfgd['use_mu_law'], np.float32)
+        assert np.array_equal(_np(out['idx']), idx_own)
+        # device-drawn noise works too (K2 identity)
+        a = eng.iaf_generate(mel, None, seed=5, want=('x', 'rand_input', 'mean_tot', 'scale_tot'))
+        k2 = _np(a['rand_input']).astype(np.float64) * _np(a['scale_tot']) + _np(a['mean_tot'])
+        assert np.abs(_np(a['x']) - k2).max() <= 2e-6 * max(1.0, np.abs(k2).max())
+    eng.close()

@@ -72,9 +72,9 @@ def test_create_without_gpu_fails_loudly_or_succeeds_on_gpu():
 
 def test_invalid_configs_are_rejected_by_the_library():
     lib = _lib.load()
-    for patch, frag in (({'filter_length': 5}, b'filter_length'), ({'width': 48}, b'specialised'),
+    for patch, frag in (({'filter_length': 5}, b'filter_length'), ({'width': 47}, b'width must be even'),
                         ({'deconv_config': [[40, 12], [80, 20]]}, b'deconv layer'),
-                        ({'num_stages': 12}, b'num_stages'), ({'num_stages': 5}, b'num_stages >= 7'),
+                        ({'num_stages': 12}, b'num_stages'), ({'num_stages': 2}, b'num_stages must be >= 3'),
                         ({'use_resize_conv': True, 'deconv_config': [[80, 10], [80, 20]]}, b'resize_conv layer')):
         d = dict(REFERENCE_STYLE_STUDENT)
         d.update(patch)
@@ -82,6 +82,16 @@ def test_invalid_configs_are_rejected_by_the_library():
         h = ctypes.c_void_p(0)
         assert lib.wn_create(ctypes.byref(c), ctypes.byref(h)) == -22
         assert frag in lib.wn_last_error(None)
+    # shapes the MFMA kernels are not specialised for are served by the generic kernels, not refused: the config check
+    # passes and only the missing GPU stops wn_create on this machine (-5), exactly as for the shipped shape
+    ok_rc = lib.wn_create(ctypes.byref(cfg.to_wn_config(cfg.load_hparams(REFERENCE_STYLE_STUDENT))), ctypes.byref(ctypes.c_void_p(0)))
+    for patch in ({'width': 48}, {'num_stages': 5}, {'width': 128, 'deconv_width': 128}):
+        c = cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, **patch)))
+        h = ctypes.c_void_p(0)
+        rc = lib.wn_create(ctypes.byref(c), ctypes.byref(h))
+        assert rc == ok_rc and rc in (0, -5)
+        if rc == 0:
+            lib.wn_destroy(h)
     assert cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, use_resize_conv=True))).use_resize_conv == 1
     c = cfg.to_wn_config(cfg.load_hparams(REFERENCE_STYLE_STUDENT))
     c.reserved[3] = 1

@@ -1,5 +1,5 @@
 """Randomised cross-checks of the execution forms against each other on the GPU (dev tool; run through
-gpurun: `python tests/tools/fuzz_gpu.py [seconds]`).  Student: auto / fused / hoisted / fp32 on random
+gpurun: `python tests/tools/fuzz_gpu.py [seconds]`).  Student: auto / fused / hoisted (layer groups forced on and off) / fp32 on random
 (batch, frames); teacher: GEMV step vs batched step vs full-sequence forward on random (batch, length)."""
 import json, os, sys, time
 import numpy as np
@@ -35,9 +35,16 @@ while time.time() < t_end:
         x = engs[p].iaf_generate(mel, a['rand_input'], want=('x',))['x']
         e = float((x - a['x']).abs().max())
         errs[p] = e if e == e else float('inf')
+    # the hoisted form with the layer-group kernel forced on / off (the default picks by call size)
+    for tag, env in (('groups', 'WN_GROUPS'), ('per-layer', 'WN_NO_GROUPS')):
+        os.environ[env] = '1'
+        x = engs['f16x3-hoisted'].iaf_generate(mel, a['rand_input'], want=('x',))['x']
+        os.environ.pop(env)
+        e = float((x - a['x']).abs().max())
+        errs[tag] = e if e == e else float('inf')
     tol = max(2e-5 * scale, 3.0 * errs['f32'])
     worst, ok = 0.0, errs['f32'] <= 1e-4 * scale
-    for p in FORMS:
+    for p in errs:
         if p != 'f32':
             worst = max(worst, errs[p])
             if not errs[p] <= tol:
