@@ -44,6 +44,8 @@ PATH_BYTES_PER_SAMPLE = 98484
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+BARRIER_KW = {}
+RED_DEV = None
 PROFILE_ROUND = 'r03'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
 DOMINANT_KERNEL = 'iaf_group_kernel'    # layer groups at one / two utterances; 'iaf_layer_c_kernel' when every layer is a launch
 GROUP_LAYERS = 5                       # residual layers per launch of the group kernel (one half of a dilation cycle)
@@ -167,7 +169,7 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier(**BARRIER_KW)
             torch.cuda.synchronize(dev)
 
     # --ramp-steps N (default 0): extra untimed steps before the W the command asked for -- a 20-step run after 3
@@ -188,7 +190,7 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
     elapsed = time.perf_counter() - t0
     layer_ms, layer_launches = eng.profile_end()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=RED_DEV or dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, layer_ms, layer_launches, wav
@@ -318,6 +320,7 @@ def main():
     ap.add_argument('--ramp-steps', type=int, default=0,
                     help='extra untimed steps before the --warmup steps (clock ramp); 0 = exactly the protocol asked for')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--same-gpu', action='store_true', help=argparse.SUPPRESS)   # N ranks on GPU 0 over gloo: code-path check on a one-GPU box
     args = ap.parse_args()
 
     rank, world, local = wdist.env_rank_world()
@@ -328,10 +331,15 @@ def main():
     if args.stub:
         return stub_main(args, rank, world, local)
     from nsynth_wavenet_amd.engine import Engine
+    if args.same_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        wdist.init_process_group('nccl')
+        wdist.init_process_group('gloo' if args.same_gpu else 'nccl')
     dev = torch.device('cuda', local)
+    global BARRIER_KW, RED_DEV
+    BARRIER_KW = {} if args.same_gpu else {'device_ids': [local]}
+    RED_DEV = torch.device('cpu') if args.same_gpu else None
 
     with open(args.config) as f:
         hp_dict = json.load(f)
@@ -339,7 +347,7 @@ def main():
     # random-init weights of the named architecture (no checkpoints offline); rank 0
     # builds them, every other rank receives them in one RCCL broadcast over xGMI
     weights = wts.synthetic_weights(hp, 'student', seed=1234, init='tf') if rank == 0 else None
-    weights = wdist.broadcast_weights(weights, hp, 'student', src=0, device=dev)
+    weights = wdist.broadcast_weights(weights, hp, 'student', src=0, device=RED_DEV or dev)
     eng = Engine(hp, kind='student', device=dev, precision=args.precision).load_weights(weights)
 
     B, F = args.batch_per_gpu, args.frames
@@ -354,7 +362,7 @@ def main():
     eng.check_range()                     # raises if a split-fp16 operand left the fp16 range during the timed calls
     seen = world
     if world > 1:                         # the world size the collective actually spans, not the environment's word
-        ws = torch.ones(1, device=dev)
+        ws = torch.ones(1, device=RED_DEV or dev)
         dist.all_reduce(ws)
         seen = int(ws.item())
 
@@ -436,7 +444,7 @@ def main():
         with open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet_gauss.json')) as f:
             hp4 = cfg.load_hparams(json.load(f))
         w4 = wts.synthetic_weights(hp4, 'student', seed=1234, init='tf') if rank == 0 else None
-        w4 = wdist.broadcast_weights(w4, hp4, 'student', src=0, device=dev)
+        w4 = wdist.broadcast_weights(w4, hp4, 'student', src=0, device=RED_DEV or dev)
         eng4 = Engine(hp4, kind='student', device=dev, precision=args.precision).load_weights(w4)
         c4 = share(eng4, 16, 888, n_s)
         eng4.close()
@@ -451,7 +459,7 @@ def main():
             rec['cpu_baseline'] = cpu_baseline(hp_dict, F)
         print(json.dumps(rec), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local])
+        dist.barrier(**BARRIER_KW)
         dist.destroy_process_group()
 
 
