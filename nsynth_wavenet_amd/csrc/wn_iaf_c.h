@@ -46,8 +46,8 @@ __device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], con
     for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            g[mg][r] = sigmoidf_(fmaf(acc[mg][r], w.inv_m, w.bg[mg * 4 + r])) *
-                       tanhf_(fmaf(acc[mg + 2][r], w.inv_m, w.bg[(mg + 2) * 4 + r]));
+            g[mg][r] = gate_scaled(fmaf(acc[mg][r], -WN_LOG2E * w.inv_m, w.bg[mg * 4 + r]),
+                                   fmaf(acc[mg + 2][r], 2.f * WN_LOG2E * w.inv_m, w.bg[(mg + 2) * 4 + r]));
     wn_u4 gh, gl;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

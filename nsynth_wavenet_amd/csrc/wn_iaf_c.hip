@@ -336,8 +336,8 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
             for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
-                               tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
+                    g[mg][r] = gate_scaled(fmaf(acc[mg][e][r], -WN_LOG2E * inv_m, bg[mg * 4 + r]),
+                                           fmaf(acc[mg + 2][e][r], 2.f * WN_LOG2E * inv_m, bg[(mg + 2) * 4 + r]));
             wn_u4 gh, gl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

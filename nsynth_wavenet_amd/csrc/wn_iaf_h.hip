@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
             for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    g[mg][r] = sigmoidf_(fmaf(acc[mg][e][r], inv_m, bg[mg * 4 + r])) *
-                               tanhf_(fmaf(acc[mg + 2][e][r], inv_m, bg[(mg + 2) * 4 + r]));
+                    g[mg][r] = gate_scaled(fmaf(acc[mg][e][r], -WN_LOG2E * inv_m, bg[mg * 4 + r]),
+                                           fmaf(acc[mg + 2][e][r], 2.f * WN_LOG2E * inv_m, bg[(mg + 2) * 4 + r]));
             wn_u4 gh, gl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -419,7 +419,8 @@ int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob) {
                 for (int mb = 0; mb < 4; ++mb)
                     for (int r = 0; r < 4; ++r) {
                         const int o = 16 * mb + 4 * q + r;
-                        tb[q * 16 + mb * 4 + r] = bd[o] + bc[o];
+                        // gate bias, pre-scaled for gate_scaled(): sigmoid rows (o < 32) by -log2(e), tanh rows by 2 log2(e)
+                        tb[q * 16 + mb * 4 + r] = (bd[o] + bc[o]) * (mb < 2 ? -1.4426950408889634f : 2.8853900817779268f);
                         tb[64 + q * 16 + mb * 4 + r] = br[o];
                     }
             tb[128] = 1.0f / sm;
