@@ -369,6 +369,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                     buf_st4<WN_L_ST_AUX>(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
                     buf_st4<WN_L_ST_AUX>(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
                 }
+                wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
             } else {
                 // ---- flow head on this column block (same arithmetic as iaf_head_c_kernel) ----
                 f4 hacc[4];
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                     buf_st4<WN_L_ST_AUX>(qh[s2], ro, vo_out, (4 * s2) * RS16);
                     buf_st4<WN_L_ST_AUX>(ql[s2], ro, vo_out, (8 + 4 * s2) * RS16);
                 }
+                wn_store_fence(qh[0], ql[0], qh[1], ql[1]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) { ph[s2] = oh[s2]; pl[s2] = ol[s2]; }

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         buf_st4(oh[s], ro, vo, (4 * s) * RS16);
                         buf_st4(ol[s], ro, vo, (8 + 4 * s) * RS16);
                     }
+                    wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
                 }
             }
             g_dma_wait();                                  // this wave's share of the next image has landed

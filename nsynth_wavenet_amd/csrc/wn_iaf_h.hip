@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 buf_st4(oh[s2], ro, vo_out + 16 * e, (4 * s2) * RS16);
                 buf_st4(ol[s2], ro, vo_out + 16 * e, (8 + 4 * s2) * RS16);
             }
+            wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
         }
     }
     wn_range_flag(amax, status);

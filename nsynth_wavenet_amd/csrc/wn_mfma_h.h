@@ -115,6 +115,18 @@ template <int AUX = 0>
 __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
 }
+// Ends a run of 16-byte stores of the words a .. d.  A wide store reads its data VGPRs some cycles after it issues; the
+// ISA manual asks for a wait state before a VALU instruction overwrites them EXCEPT for buffer stores with an SGPR
+// soffset, hipcc's hazard recognizer implements that exemption, and on gfx950 it does not hold: the group kernel lost
+// quads of lanes of `buffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen` to the `v_max_f32 v48, ...` the register
+// allocator and the scheduler had put right behind it (nondeterministic, nearly every call;
+// profiles/r03_store_hazard.txt).  The statement below READS the stored registers, so they stay allocated up to it
+// -- nothing scheduled between the stores and the statement can write them -- and its two wait states separate the
+// last store from whatever reuses them afterwards.  scripts/audit_store_hazard.py (run by tests/test_build.py)
+// checks the compiler's assembly of every kernel for the pattern.
+__device__ inline void wn_store_fence(const wn_u4& a, const wn_u4& b, const wn_u4& c, const wn_u4& d) {
+    asm volatile("s_nop 1" ::"v"(a), "v"(b), "v"(c), "v"(d));
+}
 
 
 // Operands of the FIRST residual layer of a flow (dilation 1), computed from the flow input instead

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Audit of the compiled gfx950 kernels for the wide-store data hazard.
+
+A buffer / global store of more than 64 bits reads its data VGPRs some cycles AFTER it issues.  The ISA
+manual asks for one wait state before a VALU instruction overwrites them and exempts buffer stores whose
+SOFFSET is an SGPR; LLVM's hazard recognizer implements that exemption (GCNHazardRecognizer::
+createsVALUHazard).  On gfx950 the exemption does not hold: round 3 lost quads of lanes of a
+`buffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen` to the `v_max_f32 v48, ...` right behind it
+(profiles/r03_store_hazard.txt).  The kernels therefore end every run of such stores with wn_store_fence()
+(wn_mfma_h.h); this script disassembles nothing, it reads the compiler's own .s and fails if a wide store
+is followed within WINDOW instruction slots by a VALU write of its data registers.
+
+    python scripts/audit_store_hazard.py            # compiles csrc/*.hip with -save-temps into a temp dir
+"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+WINDOW = 2          # instruction slots behind the store that must not write its data
+
+
+def regs(tok):
+    out = set()
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', tok):
+        if m.group(1):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def audit(path):
+    bad = []
+    kernel = None
+    ins = []            # (line number, text, kernel)
+    for ln, l in enumerate(open(path), 1):
+        s = l.strip()
+        m = re.match(r'^(_Z\w+):', s)
+        if m:
+            kernel = m.group(1)
+        if not s or s[0] in ';.' or s.endswith(':') or s.startswith('//'):
+            continue
+        ins.append((ln, s.split(';')[0].strip(), kernel))
+    for i, (ln, s, k) in enumerate(ins):
+        m = re.match(r'(buffer|global|scratch|flat)_store_dwordx[34]\s+(.*)', s)
+        if not m:
+            continue
+        args = [a.strip() for a in m.group(2).split(',')]
+        data = regs(args[0]) if m.group(1) == 'buffer' else regs(args[1])
+        for j in range(1, WINDOW + 1):
+            if i + j >= len(ins):
+                break
+            ln2, s2, _ = ins[i + j]
+            op = s2.split()[0]
+            if op.startswith('s_nop'):
+                n = int(s2.split()[1]) + 1
+                if j + n > WINDOW:
+                    break
+                continue
+            if not op.startswith('v_') or op.startswith('v_cmp') or op.startswith('v_mfma'):
+                if op.startswith('s_') or op.startswith('ds_') or op.startswith('buffer_') or op.startswith('global_'):
+                    continue
+            dst = s2[len(op):].split(',')[0]
+            if op.startswith('v_') and regs(dst) & data:
+                bad.append((k, ln, s, ln2, s2))
+    return bad
+
+
+def main():
+    from nsynth_wavenet_amd import build as B
+    hipcc = B.find_hipcc()
+    tmp = tempfile.mkdtemp(prefix='wn_audit_')
+    total = 0
+    srcs = [s for s in B.SOURCES if s.endswith('.hip')]
+    procs = []
+    for s in srcs:
+        d = os.path.join(tmp, s)
+        os.makedirs(d)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', os.path.join(ROOT, 'include'), '-I', B.CSRC,
+               '-save-temps', '-c', os.path.join(B.CSRC, s), '-o', 'x.o'] + os.environ.get('WN_EXTRA_FLAGS', '').split()
+        procs.append((s, d, subprocess.Popen(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for s, d, p in procs:
+        p.wait()
+        asm = [f for f in os.listdir(d) if f.endswith('gfx950.s')]
+        if not asm:
+            print('no assembly for', s)
+            total += 1
+            continue
+        bad = audit(os.path.join(d, asm[0]))
+        print('%-16s %d finding(s)' % (s, len(bad)))
+        for k, ln, st, ln2, w in bad:
+            print('   %s\n      %d: %s\n      %d: %s' % (k, ln, st, ln2, w))
+        total += len(bad)
+    return 1 if total else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
