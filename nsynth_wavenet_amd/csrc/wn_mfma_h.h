@@ -122,7 +122,7 @@ __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int 
 // allocator and the scheduler had put right behind it (nondeterministic, nearly every call;
 // profiles/r03_store_hazard.txt).  The statement below READS the stored registers, so they stay allocated up to it
 // -- nothing scheduled between the stores and the statement can write them -- and its two wait states separate the
-// last store from whatever reuses them afterwards.  scripts/audit_store_hazard.py (run by tests/test_build.py)
+// last store from whatever reuses them afterwards.  scripts/audit_store_hazard.py (run by tests/test_host.py)
 // checks the compiler's assembly of every kernel for the pattern.
 __device__ inline void wn_store_fence(const wn_u4& a, const wn_u4& b, const wn_u4& c, const wn_u4& d) {
     asm volatile("s_nop 1" ::"v"(a), "v"(b), "v"(c), "v"(d));
