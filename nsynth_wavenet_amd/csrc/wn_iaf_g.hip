@@ -106,6 +106,9 @@ __device__ inline void g_dma_image(const unsigned* src, unsigned dst, int words,
     if (rem && wave == full % nwaves && lane < rem) g_dma16(src + (size_t)(full * 64 + lane) * 4, dst + full * 1024);
 }
 __device__ inline void g_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... all but the N youngest requests of the wave
+template <int N>
+__device__ inline void g_dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A) {
@@ -218,7 +221,10 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     cn[e][mb] = buf_ldf4(rc, (cblk0 + i0 + e) * 4096 + lane * 16, mb * 1024);
         };
         load_c(A.L[0].C);
-        g_dma_wait();
+        // A K loop needs the segment and the fragment image, not the hoisted tile (added behind it): the eight C loads
+        // are the youngest requests of the wave and vmcnt retires in order, so they stay in flight across the barrier
+        // and the first K loop -- 96 of the 249 KB a workgroup asks for in its prologue, when every CU asks at once.
+        g_dma_wait_but<4 * GK_HN>();
         __syncthreads();
 
         wn_u4 fh[GK_HN][2], fl[GK_HN][2];                  // LAST: the group's output words, input of the head
@@ -230,9 +236,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[e][mb] = cn[e][mb];
-            if (!fin) load_c(A.L[j + 1].C);
-            else if (LAST) load_c(A.Ch);
+                for (int mb = 0; mb < 4; ++mb) acc[e][mb] = (f4){0.f, 0.f, 0.f, 0.f};
             if (run) {
                 // B operands: column 16 i + n - shift of the layer input, one 16-byte LDS word per (tap, half, plane)
                 int ba[GK_HN][3];
@@ -260,13 +264,21 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     }
                 }
             }
-            g_dma_wait();                                  // (the tail image requested at the top of the layer)
+            g_dma_wait();                                  // the layer's tail image and its C tile
             __syncthreads();                               // every wave has read the layer input and the fragments
             if (!fin) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
             else if (LAST) {
                 g_dma_image(A.whead, lds_base + GK_A_OFF, HC_A_WORDS, wave, lane);
                 g_dma_image(A.whead + IAF_PH_FLOATS, lds_base + GK_A_OFF + HC_A_WORDS * 4, HC_TAIL_WORDS, wave, lane);
             }
+            // the hoisted term joins behind the K loop, and its registers take the next layer's (or the head's) tile: a
+            // whole epilogue and K loop to land in
+#pragma unroll
+            for (int e = 0; e < GK_HN; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[e][mb] += cn[e][mb];
+            if (!fin) load_c(A.L[j + 1].C);
+            else if (LAST) load_c(A.Ch);
             W.inv_m = tailf[IAF_PR_FLOATS + 128];
             W.inv_r = tailf[IAF_PR_FLOATS + 129];
 #pragma unroll
@@ -305,7 +317,9 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
                 }
             }
-            g_dma_wait();                                  // this wave's share of the next image has landed
+            // this wave's share of the next image has landed (the C loads behind it stay in flight)
+            if (!fin || LAST) g_dma_wait_but<4 * GK_HN>();
+            else g_dma_wait();
             __syncthreads();                               // layer output in LDS, next image complete, tail buffer free
             if (!fin) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
         }
