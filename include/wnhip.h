@@ -32,7 +32,7 @@
  *     order).  Nothing throws or aborts across the ABI; the message is
  *     available from wn_last_error().
  *   - Concurrency.  After wn_finalize() the weights and every table of a handle are read-only, and the
- *     student calls (wn_deconv, wn_iaf_generate*, wn_iaf_range_status, wn_clip_quant) keep all per-call
+ *     student calls (wn_deconv, wn_iaf_generate*, wn_iaf_range_*, wn_clip_quant) keep all per-call
  *     state -- including the range-guard word -- in the caller's workspace: concurrent callers may share
  *     one student handle when each uses its own workspace and stream.  NOT shareable: the error string
  *     behind wn_last_error (last writer wins), the measurement aid wn_profile_* (event list on the
@@ -199,6 +199,13 @@ int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, int B, int F,
                          void* ws, size_t ws_bytes, void* stream);
 size_t wn_iaf_workspace_bytes_form(const wn_handle* h, int form, int B, int F);
 int wn_iaf_range_status(wn_handle* h, const void* ws, void* stream);
+/* A run of calls kept asynchronous (a serving or timing loop that does not want one host synchronisation per call):
+ * the second word of the workspace head accumulates the status words of every call made on that workspace.
+ * wn_iaf_range_reset(h, ws, stream) zeroes the 64-byte head (do it once for a fresh workspace and before a run);
+ * wn_iaf_range_status_since_reset(h, ws, stream) SYNCHRONISES, returns WN_ERANGE if ANY call since the reset left the
+ * fp16 range (each such call NaN-poisoned its own outputs, as above) and resets.  Both touch only the workspace. */
+int wn_iaf_range_reset(wn_handle* h, void* ws, void* stream);
+int wn_iaf_range_status_since_reset(wn_handle* h, void* ws, void* stream);
 
 /* _clip_quant_scale on its own (parallel_wavenet.py:347-359 with
  * utils.cast_quantize / inv_cast_quantize / inv_mu_law, utils.py:108-159):

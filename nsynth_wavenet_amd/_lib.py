@@ -19,7 +19,8 @@ FORM_DEFAULT, FORM_F16X3, FORM_F32, FORM_F16X3_FUSED = -1, 0, 1, 2
 # every symbol include/wnhip.h declares
 SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_iaf_length',
            'wn_ar_length', 'wn_workspace_bytes', 'wn_deconv', 'wn_iaf_generate', 'wn_iaf_generate_form',
-           'wn_iaf_workspace_bytes_form', 'wn_iaf_range_status', 'wn_clip_quant',
+           'wn_iaf_workspace_bytes_form', 'wn_iaf_range_status', 'wn_iaf_range_reset',
+           'wn_iaf_range_status_since_reset', 'wn_clip_quant',
            'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph',
            'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
 
@@ -74,6 +75,8 @@ def load():
     lib.wn_iaf_workspace_bytes_form.argtypes = [vp, i32, i32, i32]
     lib.wn_iaf_workspace_bytes_form.restype = sz
     lib.wn_iaf_range_status.argtypes = [vp, vp, vp]
+    lib.wn_iaf_range_reset.argtypes = [vp, vp, vp]
+    lib.wn_iaf_range_status_since_reset.argtypes = [vp, vp, vp]
     lib.wn_clip_quant.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.wn_ar_n_rand.argtypes = [vp]
     lib.wn_ar_state_bytes.argtypes = [vp, i32]

@@ -480,10 +480,19 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
 constexpr int DG_Q = 32;
 __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
-    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act, unsigned* __restrict__ status) {
+    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act, unsigned* __restrict__ status,
+    int zero_pads) {
     __shared__ float tile[8][DI_MAXS][DG_Q + 1];
     const int g = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * DG_Q;
+    if (zero_pads && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x)) {
+        // an intermediate layer: the next GEMM reads yoff zero words left of sample 0 and zeros right of sample S L up
+        // to the row stride -- written here instead of by a memset of the whole buffer in front of the launch
+        wn_u4* rh = reinterpret_cast<wn_u4*>(y + ((size_t)b * cout * ys)) + (size_t)g * ys;
+        wn_u4* rl = rh + (size_t)(cout / 8) * ys;
+        const int64_t lo = blockIdx.x == 0 ? 0 : yoff + (int64_t)S * L, hi = blockIdx.x == 0 ? yoff : ys;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) rh[i] = rl[i] = (wn_u4){0u, 0u, 0u, 0u};
+    }
     const int prbase = 16 * (g >> 2) + 2 * (g & 3);
     for (int i = threadIdx.x; i < 8 * S * DG_Q; i += 256) {
         const int c8 = i / (S * DG_Q), j = i - c8 * S * DG_Q;
@@ -680,12 +689,13 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             y = enc_cm; ys = enc_stride; yoff = 0;
         } else {
             y = next; ys = dc_row_stride(Lout); yoff = DC_XOFF;
-            WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
         }
         const int Q = L + (lp.pL + lp.S - 1) / lp.S + 1;      // phase columns q = (t + pL) / S
         const int Qp = ((Q + DC_QW - 1) / DC_QW) * DC_QW;
         // the fp16 GEMM of the NEXT layer reads G4 words when its input width allows it
         const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);
+        // zero pads of an intermediate output: the G4 interleave writes them itself, the other forms get a memset
+        if (!last && !next_g4) WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
         if (h_gemm) {
             dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
             const unsigned* xin = reinterpret_cast<const unsigned*>(x);
@@ -718,7 +728,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
             dim3 gi(Qp / DG_Q, lp.cout / 8, B);
             hipLaunchKernelGGL(deconv_interleave_g4_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
                                reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act,
-                               status);
+                               status, last ? 0 : 1);
         } else if (!last && h_gemm) {
             dim3 gi(Qp / DC_QT, lp.cout / 2, B);
             hipLaunchKernelGGL(deconv_interleave_split_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,

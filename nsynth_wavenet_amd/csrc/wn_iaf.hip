@@ -397,13 +397,16 @@ __global__ void iaf_final_kernel(const float* __restrict__ x0, const float* __re
                                  const float* __restrict__ St, int64_t n, int Q, int mu,
                                  float* __restrict__ wav, int* __restrict__ idx, float* __restrict__ xraw,
                                  float* __restrict__ mean_tot, float* __restrict__ scale_tot,
-                                 const unsigned* __restrict__ status) {
+                                 unsigned* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // A split-fp16 operand left the fp16 range somewhere in this call (wn_codec.h): whatever the flows computed after
     // that is not the reference's result.  Never hand it out as audio -- every float output becomes NaN, the index 0;
     // wn_iaf_range_status() reports WN_ERANGE and the caller re-runs the call with wn_iaf_generate_prec(.., 1 = fp32).
     const bool bad = *status != 0u;
+    // status[1] accumulates over the calls made on this workspace (zero_pads_kernel clears status[0] only): a caller
+    // that keeps a run of calls asynchronous asks ONCE at the end (wn_iaf_range_status_since_reset)
+    if (bad && i == 0) atomicOr(status + 1, *status);
     float s = fminf(St[i], EXP_7);                          // :327
     float m = Mt[i];
     float y = x0[i] * s + m;                                // :330
@@ -967,20 +970,37 @@ size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F, int form) {
     return n;
 }
 
+static int range_report(wn_handle* h, unsigned flag) {
+    if (flag)
+        return wn_fail(h, WN_ERANGE, "wn_iaf_generate: an activation left the fp16 range of the split-fp16 arithmetic "
+                       "(|value| >= 65504); the outputs of that call are NaN -- re-run it with "
+                       "wn_iaf_generate_form(h, WN_FORM_F32, ...)");
+    return WN_OK;
+}
+
 extern "C" int wn_iaf_range_status(wn_handle* h, const void* ws, void* stream) {
     if (!h || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_range_status: null argument");
     unsigned flag = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WN_HIP(h, hipMemcpyAsync(&flag, ws, sizeof(flag), hipMemcpyDeviceToHost, st));      // the status word leads the workspace
     WN_HIP(h, hipStreamSynchronize(st));
-    if (flag & 2u)
-        return wn_fail(h, WN_EIO, "wn_iaf_generate: a fragment slot of the layer-group kernel never became ready (LDS-DMA "
-                       "hand-off timed out); the outputs of that call are NaN.  WN_GROUP_FORM=1 selects the barrier-only form");
-    if (flag)
-        return wn_fail(h, WN_ERANGE, "wn_iaf_generate: an activation left the fp16 range of the split-fp16 arithmetic "
-                       "(|value| >= 65504); the outputs of that call are NaN -- re-run it with "
-                       "wn_iaf_generate_form(h, WN_FORM_F32, ...)");
+    return range_report(h, flag);
+}
+
+extern "C" int wn_iaf_range_reset(wn_handle* h, void* ws, void* stream) {
+    if (!h || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_range_reset: null argument");
+    WN_HIP(h, hipMemsetAsync(ws, 0, 64, reinterpret_cast<hipStream_t>(stream)));
     return WN_OK;
+}
+
+extern "C" int wn_iaf_range_status_since_reset(wn_handle* h, void* ws, void* stream) {
+    if (!h || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_range_status_since_reset: null argument");
+    unsigned flags[2] = {0, 0};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WN_HIP(h, hipMemcpyAsync(flags, ws, sizeof(flags), hipMemcpyDeviceToHost, st));
+    WN_HIP(h, hipStreamSynchronize(st));
+    if (flags[0] | flags[1]) WN_HIP(h, hipMemsetAsync(ws, 0, 64, st));
+    return range_report(h, flags[0] | flags[1]);
 }
 
 extern "C" int wn_profile_begin(wn_handle* h) {

@@ -93,9 +93,14 @@ class Engine(object):
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
+            if self._ws is not None:
+                self.check_range()        # asynchronous calls not yet asked about: their status words live in the old buffer
+            self._ws = self._last_ws = None
             try:
                 self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                if self._ws.numel() >= 64:                 # the range-guard words at its head start from zero
+                    with torch.cuda.device(self.device):
+                        self._check(self.lib.wn_iaf_range_reset(self._h, _ptr(self._ws), self._stream()))
             except torch.cuda.OutOfMemoryError as e:
                 raise MemoryError('workspace of {:.1f} GB does not fit on {} ({}); for the IAF path '
                                   "precision='f16x3-fused' needs no conditioning workspace, or split the batch"
@@ -120,7 +125,9 @@ class Engine(object):
         outputs and raises a status word.  The engine then reads that word (one 4-byte read-back, which synchronises
         the stream) and transparently re-runs the call on the fp32-MFMA form, so the caller always gets the
         reference's fp32 behaviour; `self.range_fallbacks` counts those re-runs.  check_range=False keeps the call
-        asynchronous (timing loops): call check_range() afterwards -- it raises if the LAST call overflowed."""
+        asynchronous (serving / timing loops): call check_range() afterwards -- it raises if ANY call since the last
+        check overflowed (the library accumulates the status words in the workspace; each such call NaN-poisoned its
+        own outputs)."""
         mel = self._dev(mel)
         if mel.dim() != 3 or mel.shape[2] != self.n_mel:
             raise ValueError('mel must be [batch, frames, {}], got {}'.format(self.n_mel, tuple(mel.shape)))
@@ -160,6 +167,8 @@ class Engine(object):
                 if rc == _lib.WN_ERANGE:
                     self.range_fallbacks += 1
                     run(_lib.FORM_F32)      # same seed -> the same Philox draws when the noise is device-drawn
+                    # handled here: not to be reported again by a later check_range()
+                    self._check(self.lib.wn_iaf_range_reset(self._h, _ptr(ws), self._stream()))
                 else:
                     self._check(rc)
         for k, v in (('wav', wav), ('idx', idx), ('x', xr), ('mean_tot', mt), ('scale_tot', st),
@@ -169,11 +178,12 @@ class Engine(object):
         return out
 
     def check_range(self):
-        """Raise if the last iaf_generate(check_range=False) call left the fp16 range (its outputs are NaN then)."""
+        """Raise if any iaf_generate(check_range=False) call since the last check left the fp16 range (the outputs of
+        such a call are NaN); synchronises the stream once."""
         if self._last_ws is None or self.precision == 'f32':
             return
         with torch.cuda.device(self.device):
-            self._check(self.lib.wn_iaf_range_status(self._h, _ptr(self._last_ws), self._stream()))
+            self._check(self.lib.wn_iaf_range_status_since_reset(self._h, _ptr(self._last_ws), self._stream()))
 
     def clip_quant(self, x):
         x = self._dev(x)
