@@ -477,11 +477,14 @@ __global__ __launch_bounds__(256) void deconv_interleave_split_kernel(
 // Last layer of the split-fp16 path: weave the phases AND emit the G4 layout of wn_iaf_h.hip
 // (4 pair rows interleaved per 16-byte word group).  One workgroup = one group (8 channels) x
 // 32 q columns = 32*S consecutive output samples, 16-byte stores.
+// SC: the stride as a compile-time constant (0 = run-time value): the index arithmetic of both loops divides by it
 constexpr int DG_Q = 32;
+template <int SC>
 __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
     const float* __restrict__ yp, const float* __restrict__ bias, unsigned* __restrict__ y,
-    int cout, int Qp, int64_t ys, int yoff, int L, int S, int pL, int act, unsigned* __restrict__ status,
+    int cout, int Qp, int64_t ys, int yoff, int L, int S_rt, int pL, int act, unsigned* __restrict__ status,
     int zero_pads) {
+    const int S = SC ? SC : S_rt;
     __shared__ float tile[8][DI_MAXS][DG_Q + 1];
     const int g = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * DG_Q;
@@ -494,12 +497,15 @@ __global__ __launch_bounds__(256) void deconv_interleave_g4_kernel(
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) rh[i] = rl[i] = (wn_u4){0u, 0u, 0u, 0u};
     }
     const int prbase = 16 * (g >> 2) + 2 * (g & 3);
-    for (int i = threadIdx.x; i < 8 * S * DG_Q; i += 256) {
-        const int c8 = i / (S * DG_Q), j = i - c8 * S * DG_Q;
-        const int r = j / DG_Q, q = j - r * DG_Q;
+    // 16-byte loads: a (channel, phase) row of the tile is 128 contiguous bytes of the phase-major buffer
+    for (int i = threadIdx.x; i < 8 * S * (DG_Q / 4); i += 256) {
+        const int c8 = i / (S * (DG_Q / 4)), j = i - c8 * S * (DG_Q / 4);
+        const int r = j / (DG_Q / 4), q = 4 * (j - r * (DG_Q / 4));
         const int slot = c8 >> 1;
         const int ch = 2 * (prbase + 8 * (slot >> 1) + (slot & 1)) + (c8 & 1);
-        tile[c8][r][q] = yp[(((size_t)b * S + r) * cout + ch) * Qp + q0 + q];
+        const f4 v = *reinterpret_cast<const f4*>(yp + (((size_t)b * S + r) * cout + ch) * Qp + q0 + q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[c8][r][q + k] = v[k];
     }
     __syncthreads();
     float bs[8];
@@ -726,7 +732,9 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         // consumes the split layout
         if ((last && split_out) || next_g4) {
             dim3 gi(Qp / DG_Q, lp.cout / 8, B);
-            hipLaunchKernelGGL(deconv_interleave_g4_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
+            auto ik = lp.S == 20 ? deconv_interleave_g4_kernel<20> : lp.S == 10 ? deconv_interleave_g4_kernel<10>
+                                                                                 : deconv_interleave_g4_kernel<0>;
+            hipLaunchKernelGGL(ik, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off,
                                reinterpret_cast<unsigned*>(y), lp.cout, Qp, ys, yoff, L, lp.S, lp.pL, c.upsample_act,
                                status, last ? 0 : 1);
         } else if (!last && h_gemm) {
