@@ -33,14 +33,34 @@ def audit(path):
     bad = []
     kernel = None
     ins = []            # (line number, text, kernel)
+    in_asm = set()      # indices of instructions that came from an inline-asm statement
+    asm = False
     for ln, l in enumerate(open(path), 1):
         s = l.strip()
         m = re.match(r'^(_Z\w+):', s)
         if m:
             kernel = m.group(1)
+        if s.startswith(';;#ASMSTART'):
+            asm = True
+        elif s.startswith(';;#ASMEND'):
+            asm = False
         if not s or s[0] in ';.' or s.endswith(':') or s.startswith('//'):
             continue
+        if asm:
+            in_asm.add(len(ins))
         ins.append((ln, s.split(';')[0].strip(), kernel))
+    # second rule: a VALU instruction inside an asm statement (the split-fp16 codec's v_fma_mix*) whose result an MFMA
+    # reads as an operand within two slots -- hipcc pads nothing around instructions it cannot see into
+    for i, (ln, s, k) in enumerate(ins):
+        if i not in in_asm or not s.startswith('v_'):
+            continue
+        dst = regs(s[len(s.split()[0]):].split(',')[0])
+        for j in (1, 2):
+            if i + j >= len(ins) or ins[i + j][1].startswith('s_nop'):
+                break
+            ln2, s2, _ = ins[i + j]
+            if s2.startswith('v_mfma') and dst & regs(','.join(s2.split(',')[1:])):
+                bad.append((k, ln, s, ln2, s2))
     for i, (ln, s, k) in enumerate(ins):
         m = re.match(r'(buffer|global|scratch|flat)_store_dwordx[34]\s+(.*)', s)
         if not m:
