@@ -293,7 +293,7 @@ int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
 /* 1 when wn_iaf_generate(B, F) runs the residual layers in layer groups (up to five layers per launch with the residual
  * stream in LDS: one natural and one decimated group per ten-layer dilation cycle) -- the default of the hoisted form for
- * small calls (one or two utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
+ * small calls (up to three utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
  * (or layer pair) is a launch of its own.  Environment WN_GROUPS=1 / WN_NO_GROUPS=1 force either. */
 int wn_iaf_layer_groups(const wn_handle* h, int B, int F);
 

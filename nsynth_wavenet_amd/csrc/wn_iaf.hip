@@ -940,8 +940,9 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 // view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the whole call.
 // Where it pays: the group kernel is compute-bound per CU (its halo costs 28 % more matrix and VALU work, and the two
 // do not overlap on a gfx950 SIMD, scripts/ubench/mfma_valu_overlap.hip) and wins by launching 12 times instead of
-// 52 -- + 9 % at one utterance, +- 0 at two, - 2 ... - 4 % from four on, where the per-layer launches are full.
-// Default: while a natural group has at most two segments per CU.  WN_GROUPS=1 forces it on at any batch size,
+// 52 -- end of round 3, configs[1] utterances on one box: + 13 % at one, + 7 % at two, + 2 % at three, - 1.5 % at four,
+// - 1 % at eight, where the per-layer launches keep the GPU full.
+// Default: while a natural group has at most three segments per CU.  WN_GROUPS=1 forces it on at any batch size,
 // WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
@@ -949,7 +950,7 @@ bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (ng && atoi(ng) != 0) return false;
     const char* fg = getenv("WN_GROUPS");
     if (fg && atoi(fg) != 0) return true;
-    return (int64_t)B * ((T / 16 + 19) / 20) <= 2 * (int64_t)h->num_cu;
+    return (int64_t)B * ((T / 16 + 19) / 20) <= 3 * (int64_t)h->num_cu;
 }
 
 extern "C" int wn_iaf_layer_groups(const wn_handle* h, int B, int F) {
