@@ -428,6 +428,7 @@ def main():
             mel8 = torch.from_numpy(np.random.RandomState(777).uniform(0, 1, [8, F, 80]).astype(np.float32)).to(dev)
             n8 = max(3, min(args.steps, 20))
             el8, lms8, ll8, wav8 = measure(eng, mel8, n8, 2, rank, world, local, dev, 2)
+            eng.check_range()
             r8 = roofline_of(eng, 8, F, T, lms8, ll8)
             r8.update({'batch_per_gpu': 8, 'steps': n8, 'ms_per_step': el8 / n8 * 1e3,
                        'samples_per_sec': 8 * T * n8 / el8})
@@ -439,6 +440,7 @@ def main():
         def share(engine, nb, seed, steps):
             melb = torch.from_numpy(np.random.RandomState(seed + rank).uniform(0, 1, [nb, F, 80]).astype(np.float32)).to(dev)
             el, _, _, w = measure(engine, melb, steps, 2, rank, world, local, dev, 1 << 30)
+            engine.check_range()          # the timed calls are asynchronous: one question behind them (raises on overflow)
             assert w.shape == (nb, T) and bool(torch.isfinite(w).all())
             return {'batch_per_gpu': nb, 'utterances': nb * world, 'steps': steps, 'ms_per_step': el / steps * 1e3,
                     'samples_per_sec': world * nb * T * steps / el, 'x_realtime': world * nb * T * steps / el / 16000.0}
