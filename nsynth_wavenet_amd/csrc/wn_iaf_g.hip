@@ -162,7 +162,10 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         const int blk0 = seg * A.nb_out - A.hb;                                   // unit block index of LDS block 0
         const int cblk0 = (A.in_dec ? r * A.nbu : 0) + blk0;                      // its block index inside a row block of C
         const int qcol0 = (A.in_dec ? r * A.RJ + GK_PADJ : IAF_LP) + 16 * blk0;   // its 16-byte column in a row of lin
-        const int i0 = GK_HN * wave;                                              // first LDS block of this wave
+        // LDS blocks of this wave: wave + 12 e.  The blocks a late layer skips (its `first`: the halo, blocks 0 .. 3 for
+        // the fifth layer) then belong to four different waves on four different SIMDs, so every SIMD loses one of its six
+        // blocks there; with adjacent blocks per wave two SIMDs would skip two and the barrier would wait for the others
+        auto blk_of = [&](int e) { return wave + GK_WAVES * e; };
         auto active = [&](int i) { return (unsigned)(blk0 + i) < (unsigned)A.nbu; };
         // time of column n of LDS block i
         auto time_of = [&](int i) -> int { return A.in_dec ? r + GK_DEC * (16 * (blk0 + i) + n) : 16 * (blk0 + i) + n; };
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             const float* xb = A.x + (size_t)b * A.XR + IAF_XP;
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) {
-                const int i = i0 + e, t = time_of(i);
+                const int i = blk_of(e), t = time_of(i);
                 const bool on = active(i);
                 float x0 = 0.f, x1 = 0.f, x2 = 0.f;
                 if (on) { x0 = xb[t - 3]; x1 = xb[t - 2]; x2 = xb[t - 1]; }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)      // blocks outside the row block fall outside the descriptor: zeros
-                    cn[e][mb] = buf_ldf4(rc, (cblk0 + i0 + e) * 4096 + lane * 16, mb * 1024);
+                    cn[e][mb] = buf_ldf4(rc, (cblk0 + blk_of(e)) * 4096 + lane * 16, mb * 1024);
         };
         load_c(A.L[0].C);
         // A K loop needs the segment and the fragment image, not the hoisted tile (added behind it): the eight C loads
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         for (int j = 0; j < A.nl; ++j) {
             const bool fin = j + 1 == A.nl;
             const int d = A.L[j].d;
-            const bool run = i0 + GK_HN > A.L[j].first;    // any block of this wave still needed from this layer
+            const bool run = blk_of(GK_HN - 1) >= A.L[j].first;   // any block of this wave still needed from this layer
             f4 acc[GK_HN][4];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e)
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                 for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                     for (int tap = 0; tap < 3; ++tap) {
-                        const int c = 16 * (i0 + e) + n - (2 - tap) * d;
+                        const int c = 16 * blk_of(e) + n - (2 - tap) * d;
                         ba[e][tap] = (max(c >> 4, -1) + 1) * GK_BLK_BYTES + q * 256 + (c & 15) * 16;
                     }
 #pragma unroll
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             W.inv_r = tailf[IAF_PR_FLOATS + 129];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) {
-                const int i = i0 + e;
+                const int i = blk_of(e);
                 if (i < A.L[j].first || !active(i)) continue;          // not needed / outside the utterance (stays zero)
                 char* blk = lds + (i + 1) * GK_BLK_BYTES + own;
                 wn_u4 lh[2], ll[2], oh[2], ol[2];
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             const float bmean = hf[192], bscale = hf[193], inv_h = hf[194];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) {
-                const int i = i0 + e;
+                const int i = blk_of(e);
                 if (i < A.hb || !active(i)) continue;
                 f4 hacc[4];
 #pragma unroll
