@@ -230,7 +230,6 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         g_dma_wait_but<4 * GK_HN>();
         __syncthreads();
 
-        wn_u4 fh[GK_HN][2], fl[GK_HN][2];                  // LAST: the group's output words, input of the head
         for (int j = 0; j < A.nl; ++j) {
             const bool fin = j + 1 == A.nl;
             const int d = A.L[j].d;
@@ -296,15 +295,12 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     ll[s] = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE + s * 1024);
                 }
                 pair_epilogue(W, acc[e], lh, ll, oh, ol, amax);
-                if (!fin) {
+                if (!fin || LAST) {                                    // (LAST: the head below reads its input from here)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         *reinterpret_cast<wn_u4*>(blk + s * 1024) = oh[s];
                         *reinterpret_cast<wn_u4*>(blk + GK_PLANE + s * 1024) = ol[s];
                     }
-                } else if (LAST) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) { fh[e][s] = oh[s]; fl[e][s] = ol[s]; }
                 } else {
                     // the group's output: natural order, or scattered once into the DL layout of the next (decimated) group
                     const int t = time_of(i);
@@ -344,7 +340,9 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                 for (int mb = 0; mb < 4; ++mb) hacc[mb] = cn[e][mb];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    wn_u4 bh = fh[e][ks], bl = fl[e][ks];
+                    // the group's output block, written in place by this lane in the last layer's epilogue
+                    const char* blk = lds + (i + 1) * GK_BLK_BYTES + own + ks * 1024;
+                    wn_u4 bh = *reinterpret_cast<const wn_u4*>(blk), bl = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {             // relu(l) (:256) on the reconstructed value
                         float v0, v1;
