@@ -86,6 +86,16 @@ __device__ inline void wn_split_pair_t(float x0, float x1, unsigned& hi, unsigne
     wn_split_pair(x0, x1, hi, lo);
 }
 
+// An MFMA that reads a VGPR within two issue slots of the VALU instruction that wrote it gets the OLD register content on
+// gfx950 (scripts/ubench/valu_to_mfma.hip: 0 or 1 wait state between v_fma_mixhi_f16 -- or a plain v_add_f32 -- and a
+// v_mfma reading the result as srcB: ~98 % of 2 M results differ from the padded run; 2 or more: none).  hipcc pads its own
+// VALU -> MFMA pairs but cannot see into an asm statement, and the lo words above come out of one.  Every operand built from
+// them passes through this statement on its way to an MFMA: it depends on the words (so it follows their producers), the
+// MFMA depends on it, and it holds the two wait states.  scripts/audit_store_hazard.py checks the compiled kernels for any
+// asm VALU result an MFMA reads too early.
+__device__ inline void wn_mfma_fence(wn_u4& a) { asm volatile("s_nop 1" : "+v"(a)); }
+__device__ inline void wn_mfma_fence(wn_u4& a, wn_u4& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+
 __device__ inline void wn_join_pair(unsigned hi, unsigned lo, float& x0, float& x1) {
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(hi), "v"(lo));
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(hi), "v"(lo));

@@ -56,6 +56,7 @@ __device__ inline void pair_epilogue(const PairLayer& w, const f4 (&acc)[4], con
         gh[i] = hw;
         gl[i] = lw;
     }
+    wn_mfma_fence(gl);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const f4 rc = mfma3(w.PRl[(mb * 2 + 0) * 64], w.PRl[(mb * 2 + 1) * 64], gh, gl, (f4){0.f, 0.f, 0.f, 0.f});

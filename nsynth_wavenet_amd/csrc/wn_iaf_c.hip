@@ -346,6 +346,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                 gh[i] = hw;
                 gl[i] = lw;
             }
+            wn_mfma_fence(gl);
             wn_u4 oh[2], ol[2];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                         bh[i] = hw;
                         bl[i] = lw;
                     }
+                    wn_mfma_fence(bl);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         hacc[mb] = mfma3(PHl[((ks * 4 + mb) * 2 + 0) * 64], PHl[((ks * 4 + mb) * 2 + 1) * 64], bh, bl, hacc[mb]);
@@ -678,6 +680,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                      [&](int ks) { if (!FIRST) load_bc(k + 1, ks, pred); });
             wn_u4 oh[2], ol[2];
             pair_epilogue(LA, acc, th, tl, oh, ol, amax);
+            wn_mfma_fence(ol[0], ol[1]);            // layer B contracts over them straight from these registers
             // ---- layer B ----
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb] = cb[mb];
@@ -808,6 +811,7 @@ __global__ __launch_bounds__(256, 2) void iaf_head_c_kernel(
                     bh[i] = hw;
                     bl[i] = lw;
                 }
+                wn_mfma_fence(bl);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb][e] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[mb][e]);
             }

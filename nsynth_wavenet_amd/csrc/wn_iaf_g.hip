@@ -352,6 +352,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         bh[k] = hw;
                         bl[k] = lw;
                     }
+                    wn_mfma_fence(bl);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         hacc[mb] = mfma3(PHl[((ks * 4 + mb) * 2 + 0) * 64], PHl[((ks * 4 + mb) * 2 + 1) * 64], bh, bl, hacc[mb]);

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 gh[i] = hw;
                 gl[i] = lw;
             }
+            wn_mfma_fence(gl);
             wn_u4 oh[2], ol[2];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
                         bh[i] = hw;
                         bl[i] = lw;
                     }
+                    wn_mfma_fence(bl);
                 }
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)

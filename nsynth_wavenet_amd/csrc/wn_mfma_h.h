@@ -153,6 +153,8 @@ __device__ inline void first_layer_operands(const float (&xv)[5], long long t, i
                 bc[2 * tap + s].l[0][i] = lw;
             }
         }
+#pragma unroll
+    for (int k = 0; k < 6; k += 2) wn_mfma_fence(bc[k].l[0], bc[k + 1].l[0]);     // operands of the K loop that follows
 }
 // stage (w0, w1, w2, b) per channel from the start-conv block w[3][64] | b[64]
 __device__ inline void stage_start_weights(const float* __restrict__ wb, f4* wq) {

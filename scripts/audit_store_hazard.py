@@ -10,6 +10,12 @@ createsVALUHazard).  On gfx950 the exemption does not hold: round 3 lost quads o
 (wn_mfma_h.h); this script disassembles nothing, it reads the compiler's own .s and fails if a wide store
 is followed within WINDOW instruction slots by a VALU write of its data registers.
 
+Second rule, same mechanism: an MFMA that reads a VGPR with fewer than two wait states behind the VALU instruction that
+wrote it gets the OLD register content (scripts/ubench/valu_to_mfma.hip).  hipcc pads its own VALU -> MFMA pairs, but the
+lo words of the split-fp16 codec come out of v_fma_mix* instructions inside asm statements, which it cannot see into;
+every operand built from them passes through wn_mfma_fence() (wn_codec.h).  The audit flags any asm VALU result that an
+MFMA reads earlier than that.
+
     python scripts/audit_store_hazard.py            # compiles csrc/*.hip with -save-temps into a temp dir
 """
 import os, re, subprocess, sys, tempfile
@@ -50,17 +56,21 @@ def audit(path):
             in_asm.add(len(ins))
         ins.append((ln, s.split(';')[0].strip(), kernel))
     # second rule: a VALU instruction inside an asm statement (the split-fp16 codec's v_fma_mix*) whose result an MFMA
-    # reads as an operand within two slots -- hipcc pads nothing around instructions it cannot see into
+    # reads as an operand with fewer than two wait states between them -- the MFMA then gets the OLD register content
+    # (scripts/ubench/valu_to_mfma.hip); hipcc pads nothing around instructions it cannot see into (wn_mfma_fence)
     for i, (ln, s, k) in enumerate(ins):
         if i not in in_asm or not s.startswith('v_'):
             continue
         dst = regs(s[len(s.split()[0]):].split(',')[0])
-        for j in (1, 2):
-            if i + j >= len(ins) or ins[i + j][1].startswith('s_nop'):
-                break
+        states = 0          # wait states between the write and the candidate reader (an instruction = 1, s_nop N = N + 1)
+        j = 1
+        while states < 2 and i + j < len(ins):
             ln2, s2, _ = ins[i + j]
             if s2.startswith('v_mfma') and dst & regs(','.join(s2.split(',')[1:])):
                 bad.append((k, ln, s, ln2, s2))
+                break
+            states += int(s2.split()[1]) + 1 if s2.startswith('s_nop') else 1
+            j += 1
     for i, (ln, s, k) in enumerate(ins):
         m = re.match(r'(buffer|global|scratch|flat)_store_dwordx[34]\s+(.*)', s)
         if not m:

@@ -35,7 +35,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert _lib.load().wn_abi_version() == 1
 
 
-def test_compiled_kernels_are_free_of_the_wide_store_data_hazard(tmp_path):
+def test_compiled_kernels_are_free_of_the_hazards_hipcc_does_not_guard(tmp_path):
     """gfx950 loses lanes of a buffer_store_dwordx4 whose data register is overwritten by the VALU instruction behind
     it, a form hipcc's hazard recognizer exempts (profiles/r03_store_hazard.txt): the audit reads the compiler's own
     assembly of every kernel source and must come back empty; it must also SEE the pattern in a crafted listing."""
@@ -50,6 +50,16 @@ def test_compiled_kernels_are_free_of_the_wide_store_data_hazard(tmp_path):
                        '\t;;#ASMEND\n\tv_max_f32_e64 v48, |v84|, |v85|\n\ts_endpgm\n')
     found = audit.audit(str(crafted))
     assert len(found) == 1 and found[0][0] == '_Zkernel'
+    # second rule: an MFMA reading the result of a VALU instruction inside an asm statement with fewer than two wait
+    # states between them (scripts/ubench/valu_to_mfma.hip: it gets the old register content)
+    crafted.write_text('_Zearly:\n\t;;#ASMSTART\n\tv_fma_mixhi_f16 v87, v51, -1.0, v88 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t;;#ASMEND\n'
+                       '\tv_mov_b32_e32 v88, v97\n\tv_mfma_f32_16x16x32_f16 v[100:103], v[80:83], v[84:87], v[60:63]\n\ts_endpgm\n'
+                       '_Zpadded:\n\t;;#ASMSTART\n\tv_fma_mixhi_f16 v87, v51, -1.0, v88 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t;;#ASMEND\n'
+                       '\t;;#ASMSTART\n\ts_nop 1\n\t;;#ASMEND\n\tv_mfma_f32_16x16x32_f16 v[100:103], v[80:83], v[84:87], v[60:63]\n\ts_endpgm\n'
+                       '_Zone_state:\n\t;;#ASMSTART\n\tv_fma_mixhi_f16 v87, v51, -1.0, v88 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t;;#ASMEND\n'
+                       '\ts_nop 0\n\tv_mfma_f32_16x16x32_f16 v[100:103], v[80:83], v[84:87], v[60:63]\n\ts_endpgm\n')
+    found = audit.audit(str(crafted))
+    assert sorted(f[0] for f in found) == ['_Zearly', '_Zone_state']
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'audit_store_hazard.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(' 0 finding(s)') >= 9
