@@ -66,7 +66,9 @@ def audit(path):
         j = 1
         while states < 2 and i + j < len(ins):
             ln2, s2, _ = ins[i + j]
-            if s2.startswith('v_mfma') and dst & regs(','.join(s2.split(',')[1:])):
+            op2 = s2.split()[0]
+            # (a DPP instruction reading a freshly written VGPR needs the same two states: also flagged)
+            if (op2.startswith('v_mfma') or op2.endswith('_dpp')) and dst & regs(','.join(s2.split(',')[1:])):
                 bad.append((k, ln, s, ln2, s2))
                 break
             states += int(s2.split()[1]) + 1 if s2.startswith('s_nop') else 1
