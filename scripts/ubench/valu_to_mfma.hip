@@ -59,6 +59,41 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     out[(blockIdx.x * blockDim.x + threadIdx.x) * 4 + 3] = acc[3];
 }
 
+// the codec's two halves: v_fma_mixlo_f16 writes the low 16 bits of a register, v_fma_mixhi_f16 the high 16 bits of the
+// same register right behind it -- does the second one keep what the first one wrote when they issue back to back?
+template <int PAD>
+__global__ __launch_bounds__(256) void k2(unsigned* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned sum = 0;
+    for (int it = 0; it < iters; ++it) {
+        float x0 = 0.37f * (lane + 1) + 1e-3f * it, x1 = -0.11f * (lane + 3) + 2e-3f * it;
+        unsigned hi, l;
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(hi) : "v"(x0), "v"(x1));
+        if (PAD)
+            asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\ts_nop 3\n\t"
+                         "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 3"
+                         : "=&v"(l) : "v"(hi), "v"(x0), "v"(x1));
+        else
+            asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 3"
+                         : "=&v"(l) : "v"(hi), "v"(x0), "v"(x1));
+        sum = sum * 1664525u + l;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+template <int PAD>
+static std::vector<unsigned> run2(int blocks, int iters) {
+    const size_t n = (size_t)blocks * 256;
+    unsigned* d;
+    (void)hipMalloc(&d, n * 4);
+    hipLaunchKernelGGL(k2<PAD>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned> h(n);
+    (void)hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return h;
+}
+
 template <int MODE>
 static std::vector<float> run(int blocks, int iters) {
     const size_t n = (size_t)blocks * 256 * 4;
@@ -89,5 +124,11 @@ int main() {
     printf("op_sel producer, 6 wait states : %zu differ\n", diff(run<6>(blocks, iters), ref));
     printf("op_sel producer, 8 wait states : %zu differ\n", diff(run<8>(blocks, iters), ref));
     printf("v_add_f32 producer, 0 wait states vs 16: %zu differ\n", diff(run<300>(blocks, iters), run<301>(blocks, iters)));
+    {
+        const auto a = run2<0>(blocks, iters), b = run2<1>(blocks, iters);
+        size_t bad = 0;
+        for (size_t i = 0; i < a.size(); ++i) bad += a[i] != b[i];
+        printf("mixlo -> mixhi of one register back to back vs 4 wait states apart: %zu of %zu lane checksums differ\n", bad, a.size());
+    }
     return 0;
 }
