@@ -316,7 +316,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the second roofline block (8 utterances per GPU) and the PCIe-inclusive timing')
-    ap.add_argument('--layer-events-every', type=int, default=10,
+    ap.add_argument('--layer-events-every', type=int, default=20,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
