@@ -187,7 +187,9 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
     wav = None
     for i in range(steps):
         # the event pairs around the layer kernels cost the stream a bubble each: sample them
-        eng.profile_pause(i % max(events_every, 1) != 0)
+        # (not in the first step of a period: step 0 starts on an idle GPU that catches up with the host's launches)
+        n_ev = max(1, min(events_every, steps))
+        eng.profile_pause(i % n_ev != n_ev // 2)
         wav = step(warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
