@@ -376,6 +376,12 @@ def main():
         total_samples = world * B * T * args.steps
         value = total_samples / elapsed
         roof = roofline_of(eng, B, F, T, layer_ms, layer_launches)
+        # the whole call against SURVEY.md 8(d)'s layer-granular traffic model (98 484 B per generated sample; its
+        # "60 % of the HBM roofline" is 48.7 M samples/s per GPU) -- beside the dominant kernel's own figures
+        gbps = PATH_BYTES_PER_SAMPLE * (total_samples / world) / elapsed / 1e9
+        roof['path_8d_view'] = {'bytes_per_sample': PATH_BYTES_PER_SAMPLE, 'GBps': gbps, 'frac': gbps / 8000.0,
+                                'note': 'whole generate call, SURVEY 8(d) accounting (every layer reads l and enc and '
+                                        'writes l once); the shipped launch structure moves fewer bytes than this model'}
         dtype = 'f32' if eng.precision == 'f32' else \
             'split-fp16: activations stored as fp16 hi+lo pairs (32 bits per value, 22-bit significand, fp16 exponent ' \
             'range), contractions as 3 fp16 MFMAs per product with fp32 accumulate; conditioning term and outputs fp32'
