@@ -127,7 +127,8 @@ int wn_abi_version(void);
 /* Build an empty engine for one model on the current HIP device.
  * Replaces graph construction (parallelgen.py:11-19, fastgen.py:61-66,118-125).
  * Students of the shipped shape (width 64, deconv_width 256, num_stages >= 7) run on the MFMA kernels; any other even
- * width <= 1024 / deconv_width % 64 == 0 / num_stages >= 3 on generic fp32 kernels (same results, much slower).
+ * width <= 416 (one tile of the generic layer kernel must fit the 160 KB of LDS) / deconv_width % 64 == 0 /
+ * num_stages >= 3 on generic fp32 kernels (same results, much slower).
  * Teachers need 3 * width + deconv_width <= 2048. */
 int wn_create(const wn_config* cfg_host, wn_handle** out);
 
@@ -152,7 +153,10 @@ int64_t wn_iaf_length(const wn_handle* h, int F);
 int64_t wn_ar_length(const wn_handle* h, int F);
 
 /* Bytes of caller-provided scratch needed by wn_deconv / wn_iaf_generate /
- * wn_ar_generate for batch B and F frames (Tn = wn_ar_length for AR). */
+ * wn_ar_generate for batch B and F frames (Tn = wn_ar_length for AR).
+ * The first 256 bytes of a workspace hold the range-guard words of the generate calls made on it
+ * (wn_iaf_range_status*); every call -- wn_deconv included -- leaves them to those functions, so one buffer can
+ * serve wn_iaf_generate and wn_deconv in any order. */
 size_t wn_workspace_bytes(const wn_handle* h, int B, int F);
 
 /* Wavenet.deconv_stack (wavenet.py:46-73,142-155): mel [B,F,n_mel] ->
@@ -299,10 +303,12 @@ int wn_iaf_layer_groups(const wn_handle* h, int B, int F);
 
 /* Measurement aid used by bench.py (not part of the reference's surface, not
  * thread-safe).  Between begin and end, wn_iaf_generate records a hipEvent pair
- * on the caller's stream around every flow's run of residual-layer kernels
- * (iaf_layer_kernel).  wn_profile_end synchronises those events and returns the
- * summed elapsed milliseconds and the number of layer-kernel launches they
- * bracket, so that average launch duration = layer_ms / layer_launches..
+ * on the caller's stream around every flow's run of residual-stack launches --
+ * whatever form the call takes: iaf_group_kernel (layer groups, the default of small
+ * calls), iaf_layer_c_kernel / iaf_pair_c_kernel (one / two layers per launch),
+ * iaf_layer_h_kernel (fused form), iaf_layer_kernel (fp32 form).  wn_profile_end
+ * synchronises those events and returns the summed elapsed milliseconds and the
+ * number of launches they bracket: average launch duration = layer_ms / layer_launches.
  * Every recorded event costs the stream a bubble of a few microseconds, so
  * wn_profile_pause(h, 1) suspends the recording for the following calls (0 resumes):
  * bench.py samples every few steps of its timed region instead of all of them. */

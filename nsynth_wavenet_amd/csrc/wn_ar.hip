@@ -1767,7 +1767,7 @@ extern "C" int wn_ar_set_graph(wn_handle* h, int enable) {
 
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F) {
     const int64_t Tn = wn_ar_length(h, F);
-    const size_t dec = align_up((size_t)B * h->cfg.deconv_width * Tn * sizeof(float), 256) +
+    const size_t dec = WN_WS_HEAD + align_up((size_t)B * h->cfg.deconv_width * Tn * sizeof(float), 256) +
                        wn_deconv_scratch_bytes(h, B, F);
     const size_t ar = wn_ar_state_bytes(h, B);
     return dec > ar ? dec : ar;

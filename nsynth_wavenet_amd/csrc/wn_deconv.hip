@@ -768,12 +768,14 @@ extern "C" int wn_deconv(wn_handle* h, const char* scope, const float* mel, int 
     if (si < 0) return wn_fail(h, WN_ENOENT, "wn_deconv: no deconv stack with scope '%s'", scope ? scope : "");
     const int64_t Tn = (int64_t)F * h->frame_shift;
     const size_t cm_bytes = align_up((size_t)B * h->cfg.deconv_width * Tn * sizeof(float), 256);
-    const size_t need = cm_bytes + wn_deconv_scratch_bytes(h, B, F);
+    // The first WN_WS_HEAD bytes of a workspace are the range-guard words of the generate calls made on it
+    // (wn_iaf_range_status*): a student's wn_deconv on the SAME buffer must leave them alone.
+    const size_t need = WN_WS_HEAD + cm_bytes + wn_deconv_scratch_bytes(h, B, F);
     if (ws_bytes < need)
         return wn_fail(h, WN_ENOMEM, "wn_deconv: workspace %zu < %zu bytes", ws_bytes, need);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* cm = reinterpret_cast<float*>(ws);
-    int rc = wn_run_deconv(h, si, mel, B, F, cm, Tn, reinterpret_cast<char*>(ws) + cm_bytes, st);
+    float* cm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WN_WS_HEAD);
+    int rc = wn_run_deconv(h, si, mel, B, F, cm, Tn, reinterpret_cast<char*>(ws) + WN_WS_HEAD + cm_bytes, st);
     if (rc) return rc;
     dim3 g((unsigned)((Tn + 31) / 32), (h->cfg.deconv_width + 31) / 32, B);
     hipLaunchKernelGGL(cm_to_tm_kernel, g, dim3(256), 0, st, cm, enc, h->cfg.deconv_width, Tn, Tn);

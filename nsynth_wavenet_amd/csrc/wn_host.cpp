@@ -112,9 +112,12 @@ static int validate(const wn_config& c) {
         if (c.num_stages < 3)
             return wn_fail(nullptr, WN_EINVAL, "config: student num_stages must be >= 3 (the output length is a multiple of "
                            "2^(num_stages-1) and the noise / quantiser kernels move four samples at a time), got %d", c.num_stages);
-        if (c.width < 2 || (c.width & 1) || c.width > 1024 || c.deconv_width > 2048)
-            return wn_fail(nullptr, WN_EINVAL, "config: student width must be even and <= 1024, deconv_width <= 2048; "
-                           "got width %d deconv %d", c.width, c.deconv_width);
+        // generic kernels (wn_iaf_x.hip): a 64-column tile of `pre` (width rows) and `g` (width / 2 rows) lives in LDS:
+        // 1.5 * width * 256 B <= 160 KB
+        if (c.width < 2 || (c.width & 1) || c.width > 416 || c.deconv_width > 2048)
+            return wn_fail(nullptr, WN_EINVAL, "config: student width must be even and <= 416 (one tile of the generic layer "
+                           "kernel must fit the 160 KB of LDS), deconv_width <= 2048; got width %d deconv %d", c.width,
+                           c.deconv_width);
         if (c.n_flows < 1 || c.n_flows > WN_MAX_FLOWS)
             return wn_fail(nullptr, WN_EINVAL, "config: num_iaf_layers needs 1..%d flows", WN_MAX_FLOWS);
         if (c.loss_type != WN_LOSS_LOGISTIC && c.loss_type != WN_LOSS_GAUSS)
@@ -173,6 +176,12 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
             h->hoist_limit_bytes = std::min(h->hoist_limit_bytes, (double)free_b * 0.5);
+    }
+    {   // A/B switches of the layer-group kernel, read ONCE (a handle may be shared by concurrent callers)
+        const char* ng = getenv("WN_NO_GROUPS");
+        const char* fg = getenv("WN_GROUPS");
+        if (ng && atoi(ng) != 0) h->groups_env = -1;
+        else if (fg && atoi(fg) != 0) h->groups_env = 1;
     }
     if (const char* e = getenv("WN_COND")) {                         // read ONCE: sizing and generate calls must agree
         if (!strcmp(e, "fused")) h->cond_env_mode = WN_COND_FUSED;
@@ -278,6 +287,12 @@ extern "C" int wn_finalize(wn_handle* h) {
     WN_HIP(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     if (h->cfg.kind == WN_KIND_TEACHER) {
         rc = wn_ar_post_upload(h);
+        if (rc) return rc;
+    }
+    // dynamic-LDS limits of the student kernels belong to the handle's device: raised here, once, so that generate calls
+    // write nothing into the handle (a finalized handle may be shared by concurrent callers)
+    if (h->cfg.kind == WN_KIND_STUDENT) {
+        rc = wn_iaf_set_attrs(h);
         if (rc) return rc;
     }
     // host copies are no longer needed

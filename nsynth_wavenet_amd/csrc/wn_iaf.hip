@@ -85,17 +85,19 @@ __global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __
 __global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
                                  float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status,
                                  int dl_rj) {
-    const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row == 0 && c == 0 && blockIdx.z == 0) *status = 0u;        // range-guard word of this call (wn_codec.h)
-    if (blockIdx.z < 2) {
-        float* p = blockIdx.z ? lB : lA;
-        if (blockIdx.z == 1 && dl_rj > 0) {
-            // 32 x 64 words x 4 floats = pad floats again: float c -> residue c / 256, float c % 256 of its pad
-            if (row < rows && c < pad) p[(size_t)row * rs + (size_t)(c >> 8) * dl_rj * 4 + (c & 255)] = 0.f;
-        } else if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
-    } else if (row < xrows && c < xpad) {
-        x[(size_t)row * xrs + c] = 0.f;
+    if (blockIdx.y == 0 && c == 0 && blockIdx.z == 0) *status = 0u;  // range-guard word of this call (wn_codec.h)
+    // grid.y is capped (65 535 rows per launch dimension): rows are walked
+    for (int row = blockIdx.y; row < max(rows, xrows); row += gridDim.y) {
+        if (blockIdx.z < 2) {
+            float* p = blockIdx.z ? lB : lA;
+            if (blockIdx.z == 1 && dl_rj > 0) {
+                // 32 x 64 words x 4 floats = pad floats again: float c -> residue c / 256, float c % 256 of its pad
+                if (row < rows && c < pad) p[(size_t)row * rs + (size_t)(c >> 8) * dl_rj * 4 + (c & 255)] = 0.f;
+            } else if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
+        } else if (row < xrows && c < xpad) {
+            x[(size_t)row * xrs + c] = 0.f;
+        }
     }
 }
 
@@ -609,13 +611,9 @@ static int iaf_generate_generic(wn_handle* h, const IafLayout& L, const float* m
     float* St = reinterpret_cast<float*>(base + L.S);
     unsigned* status = reinterpret_cast<unsigned*>(base + L.status);
     void* scratch = base + L.scratch;
-    if (!h->iaf_attrs_set) {
-        if (int rc = wn_iaf_x_set_attrs(h)) return rc;
-        h->iaf_attrs_set = true;
-    }
     {
         const int rows = B * c.width;
-        dim3 g((IAF_LP + 255) / 256, rows, 3);
+        dim3 g((IAF_LP + 255) / 256, std::min(rows, 32768), 3);
         hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, L.RS, IAF_LP, rows, x, (int64_t)L.XR, IAF_XP, 2 * B,
                            status, 0);
     }
@@ -699,21 +697,6 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         return iaf_generate_generic(h, L, mel, B, F, noise, seed, wav, idx, x_raw, mean_tot, scale_tot, rand_out, base, st);
     const int prec = wn_form_precision(h, form);
     const bool f16x3 = prec == WN_PREC_F16X3;
-    if (!h->iaf_attrs_set) {       // per handle: function attributes belong to the handle's device
-        int rc = wn_iaf_h_set_attrs(h);
-        if (rc) return rc;
-        rc = wn_iaf_c_set_attrs(h);
-        if (rc) return rc;
-        rc = wn_iaf_g_set_attrs(h);
-        if (rc) return rc;
-        WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      IAF_LAYER_FLOATS * sizeof(float)));
-        WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      IAF_HEAD_FLOATS * sizeof(float)));
-        h->iaf_attrs_set = true;
-    }
 
     const bool use_groups = f16x3 && wn_iaf_use_groups(h, B, L.T, L.form);
     // zero left pads
@@ -722,7 +705,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         const int rows = f16x3 ? B * 16 : B * IAF_W;
         const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
         const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
-        dim3 g((pad + 255) / 256, rows, 3);
+        dim3 g((pad + 255) / 256, std::min(std::max(rows, 2 * B), 32768), 3);
         hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, 2 * B, status,
                            use_groups ? 64 + (int)(L.T / 32) : 0);
     }
@@ -916,7 +899,23 @@ int wn_form_precision(const wn_handle* h, int form) {
     return form == WN_FORM_F32 ? WN_PREC_F32 : form == WN_FORM_DEFAULT ? h->cfg.precision : WN_PREC_F16X3;
 }
 
+int wn_iaf_set_attrs(wn_handle* h) {
+    if (h->generic_student) return wn_iaf_x_set_attrs(h);
+    int rc = wn_iaf_h_set_attrs(h);
+    if (rc) return rc;
+    rc = wn_iaf_c_set_attrs(h);
+    if (rc) return rc;
+    rc = wn_iaf_g_set_attrs(h);
+    if (rc) return rc;
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_FLOATS * sizeof(float)));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * sizeof(float)));
+    return WN_OK;
+}
+
 int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form) {
+    if (h->generic_student) return WN_COND_FUSED;               // fp32 kernels of wn_iaf_x.hip: no projected term
     if (wn_form_precision(h, form) != WN_PREC_F16X3 || form == WN_FORM_F16X3_FUSED) return WN_COND_FUSED;
     int mode = h->cfg.cond_mode;
     if (mode == WN_COND_AUTO) mode = h->cond_env_mode;           // WN_COND, resolved once in wn_create
@@ -946,10 +945,7 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 // WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
-    const char* ng = getenv("WN_NO_GROUPS");
-    if (ng && atoi(ng) != 0) return false;
-    const char* fg = getenv("WN_GROUPS");
-    if (fg && atoi(fg) != 0) return true;
+    if (h->groups_env) return h->groups_env > 0;                // WN_NO_GROUPS / WN_GROUPS, resolved once in wn_create
     return (int64_t)B * ((T / 16 + 19) / 20) <= 3 * (int64_t)h->num_cu;
 }
 

@@ -33,6 +33,10 @@
 #include "wn_mfma_h.h"
 #include "wn_iaf_c.h"
 
+#ifndef GK_ABL
+#define GK_ABL 0      // TEMPORARY measurement switch (bits): results are WRONG when set
+#endif
+
 namespace {
 
 // Twelve waves (three per SIMD) of two blocks each: measured 2-4 % faster than eight waves of three blocks at every
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[e][mb] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (run) {
+            if (run && !(GK_ABL & 8)) {
                 // B operands: column 16 i + n - shift of the layer input, one 16-byte LDS word per (tap, half, plane)
                 int ba[GK_HN][3];
 #pragma unroll
@@ -262,13 +266,16 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         const wn_u4 bh = *reinterpret_cast<const wn_u4*>(lds + ba[e][ks >> 1] + (ks & 1) * 1024);
                         const wn_u4 bl = *reinterpret_cast<const wn_u4*>(lds + GK_PLANE + ba[e][ks >> 1] + (ks & 1) * 1024);
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) acc[e][mb] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[e][mb]);
+                        for (int mb = 0; mb < 4; ++mb) {
+                            if (GK_ABL & 16) acc[e][mb] = mfma_h(a[mb][0], bh, acc[e][mb]);
+                            else acc[e][mb] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[e][mb]);
+                        }
                     }
                 }
             }
             g_dma_wait();                                  // the layer's tail image and its C tile
             __syncthreads();                               // every wave has read the layer input and the fragments
-            if (!fin) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
+            if (!fin) { if (!(GK_ABL & 1)) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane); }
             else if (LAST) {
                 g_dma_image(A.whead, lds_base + GK_A_OFF, HC_A_WORDS, wave, lane);
                 g_dma_image(A.whead + IAF_PH_FLOATS, lds_base + GK_A_OFF + HC_A_WORDS * 4, HC_TAIL_WORDS, wave, lane);
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[e][mb] += cn[e][mb];
-            if (!fin) load_c(A.L[j + 1].C);
+            if (!fin) { if (!(GK_ABL & 2)) load_c(A.L[j + 1].C); }
             else if (LAST) load_c(A.Ch);
             W.inv_m = tailf[IAF_PR_FLOATS + 128];
             W.inv_r = tailf[IAF_PR_FLOATS + 129];
@@ -294,6 +301,10 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     lh[s] = *reinterpret_cast<const wn_u4*>(blk + s * 1024);
                     ll[s] = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE + s * 1024);
                 }
+                if (GK_ABL & 4) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { oh[s] = lh[s] ^ __builtin_bit_cast(wn_u4, acc[e][s]); ol[s] = ll[s] ^ __builtin_bit_cast(wn_u4, acc[e][2 + s]); }
+                } else
                 pair_epilogue(W, acc[e], lh, ll, oh, ol, amax);
                 if (!fin || LAST) {                                    // (LAST: the head below reads its input from here)
 #pragma unroll
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             if (!fin || LAST) g_dma_wait_but<4 * GK_HN>();
             else g_dma_wait();
             __syncthreads();                               // layer output in LDS, next image complete, tail buffer free
-            if (!fin) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
+            if (!fin && !(GK_ABL & 1)) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
         }
 
         if (LAST) {

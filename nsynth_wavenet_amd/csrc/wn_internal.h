@@ -120,7 +120,7 @@ struct wn_handle {
     wn_config cfg;
     std::map<std::string, HostTensor> vars;   // expected variables (+ data once set)
     bool finalized = false;
-    bool iaf_attrs_set = false;               // dynamic-LDS limits of the IAF kernels raised on this device
+
     int device = 0;
     float* d_blob = nullptr;
     size_t blob_floats = 0;
@@ -145,6 +145,7 @@ struct wn_handle {
     int num_cu = 256;
     // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
     int cond_env_mode = 0;                    // WN_COND_AUTO or the form named by the environment
+    int groups_env = 0;                       // WN_GROUPS=1 -> +1 (always), WN_NO_GROUPS=1 -> -1 (never), else 0 (policy)
     double hoist_limit_bytes = 96e9;          // a third of the device memory
     mutable std::string err;
     // cached hipGraph for the AR step (wn_ar.hip)
@@ -192,6 +193,9 @@ constexpr int WN_COND_HOISTED = 2; // one GEMM per deconv stack writes them for 
 constexpr int IAF_LP = 2048;   // zero left pad of activation rows (>= 2 * max dilation; >= 32 * 64: the DL layout of
                                // wn_iaf_g.hip keeps 64 zero columns in front of each of its 32 residue rows)
 constexpr int IAF_XP = 64;     // zero left pad of the flow input x (>= filter_length)
+// First bytes of every caller-owned workspace: the range-guard words of the generate calls made on it (status[0] of the
+// current call, status[1] accumulated since wn_iaf_range_reset).  Nothing else -- wn_deconv included -- writes there.
+constexpr size_t WN_WS_HEAD = 256;
 
 // ---- implemented in the .hip units ----
 int wn_pack_deconv(wn_handle* h, std::vector<float>& blob);
@@ -245,6 +249,7 @@ bool wn_iaf_c_pair_ok(int da, int db);
 // ---- layer groups resident in LDS (wn_iaf_g.hip) ----
 bool wn_iaf_g_plan(const std::vector<int>& dilations, std::vector<WnGroup>& out);
 int wn_iaf_g_set_attrs(wn_handle* h);
+int wn_iaf_set_attrs(wn_handle* h);   // every student kernel's dynamic-LDS limit, once per handle (wn_finalize)
 void wn_iaf_g_run(const wn_handle* h, const WnGroup& g, const IafLayerPack* layers, const float* Cg, size_t rb_floats,
                   int64_t c_bstride, const float* lin, float* lout, int64_t RS, int out_dec, int B, int64_t T,
                   const float* x, int XR, const float* wstart, bool last, const float* whead, const float* xin,

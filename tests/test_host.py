@@ -105,6 +105,8 @@ def test_invalid_configs_are_rejected_by_the_library():
     for patch, frag in (({'filter_length': 5}, b'filter_length'), ({'width': 47}, b'width must be even'),
                         ({'deconv_config': [[40, 12], [80, 20]]}, b'deconv layer'),
                         ({'num_stages': 12}, b'num_stages'), ({'num_stages': 2}, b'num_stages must be >= 3'),
+                        # the generic layer kernel keeps 1.5 * width * 256 B of a tile in LDS: 418 would need 160.5 KB
+                        ({'width': 418}, b'must fit the 160 KB'), ({'width': 1024}, b'must fit the 160 KB'),
                         ({'use_resize_conv': True, 'deconv_config': [[80, 10], [80, 20]]}, b'resize_conv layer')):
         d = dict(REFERENCE_STYLE_STUDENT)
         d.update(patch)
@@ -115,7 +117,7 @@ def test_invalid_configs_are_rejected_by_the_library():
     # shapes the MFMA kernels are not specialised for are served by the generic kernels, not refused: the config check
     # passes and only the missing GPU stops wn_create on this machine (-5), exactly as for the shipped shape
     ok_rc = lib.wn_create(ctypes.byref(cfg.to_wn_config(cfg.load_hparams(REFERENCE_STYLE_STUDENT))), ctypes.byref(ctypes.c_void_p(0)))
-    for patch in ({'width': 48}, {'num_stages': 5}, {'width': 128, 'deconv_width': 128}):
+    for patch in ({'width': 48}, {'num_stages': 5}, {'width': 128, 'deconv_width': 128}, {'width': 416}):
         c = cfg.to_wn_config(cfg.load_hparams(dict(REFERENCE_STYLE_STUDENT, **patch)))
         h = ctypes.c_void_p(0)
         rc = lib.wn_create(ctypes.byref(c), ctypes.byref(h))
