@@ -58,16 +58,19 @@ typedef _Float16 wn_h2 __attribute__((ext_vector_type(2)));
 typedef unsigned wn_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
 
-// (x0, x1) -> hi word {f16(x0), f16(x1)} and lo word of the remainders.  The remainder x - hi is
-// exact in fp32, so v_fma_mix{lo,hi}_f16 (f16 source widened inside the FMA, result rounded once to
-// f16) gives the same bits as convert / subtract / convert in half the instructions; same for the
-// join with v_fma_mix_f32 (checked bit for bit on the device: scripts/ubench/split_codec.hip).
+// (x0, x1) -> hi word {f16(x0), f16(x1)} and lo word of the remainders, in plain C++ (convert / subtract / convert):
+// x - hi is exact in fp32, so the remainder is rounded ONCE to f16.  Round 3 used v_fma_mix{lo,hi}_f16 from inline asm
+// (the same bits in fewer instructions, scripts/ubench/split_codec.hip); round 4 measured what those cost on gfx950:
+// a v_fma_mix* occupies a SIMD ~8.6 cycles like a transcendental, a plain VALU operation ~2.7
+// (profiles/r04_issue_overlap_ubench.txt; the residual epilogue alone 1 276 -> 1 198 cycles per block, 1 061 with its
+// blocks in lock step: profiles/r04_epilogue_cost.txt).  And the compiler SEES these producers: the wait states
+// gfx950 needs between a VALU write and an MFMA that reads the register (scripts/ubench/valu_to_mfma.hip) are inserted
+// by its hazard recognizer for every consumer, present and future -- the use-site fences the asm form needed are gone.
 __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, (wn_h2){(_Float16)x0, (_Float16)x1});
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
-    lo = l;
+    const wn_h2 h = {(_Float16)x0, (_Float16)x1};
+    const wn_h2 l = {(_Float16)(x0 - (float)h.x), (_Float16)(x1 - (float)h.y)};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 // Range guard of the split representation: hi = f16(x) is +-inf from |x| >= 65520 on (and the lo half NaN), where the
@@ -86,16 +89,8 @@ __device__ inline void wn_split_pair_t(float x0, float x1, unsigned& hi, unsigne
     wn_split_pair(x0, x1, hi, lo);
 }
 
-// An MFMA that reads a VGPR within two issue slots of the VALU instruction that wrote it gets the OLD register content on
-// gfx950 (scripts/ubench/valu_to_mfma.hip: 0 or 1 wait state between v_fma_mixhi_f16 -- or a plain v_add_f32 -- and a
-// v_mfma reading the result as srcB: ~98 % of 2 M results differ from the padded run; 2 or more: none).  hipcc pads its own
-// VALU -> MFMA pairs but cannot see into an asm statement, and the lo words above come out of one.  Every operand built from
-// them passes through this statement on its way to an MFMA: it depends on the words (so it follows their producers), the
-// MFMA depends on it, and it holds the two wait states.  scripts/audit_store_hazard.py checks the compiled kernels for any
-// asm VALU result an MFMA reads too early.
-__device__ inline void wn_mfma_fence(wn_u4& a) { asm volatile("s_nop 1" : "+v"(a)); }
-__device__ inline void wn_mfma_fence(wn_u4& a, wn_u4& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
-
+// The join stays on v_fma_mix_f32 (one instruction per value; its result feeds VALU arithmetic, never an MFMA operand
+// directly, so no hardware hazard hides behind the asm statement).
 __device__ inline void wn_join_pair(unsigned hi, unsigned lo, float& x0, float& x1) {
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(hi), "v"(lo));
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(hi), "v"(lo));

@@ -346,7 +346,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                 gh[i] = hw;
                 gl[i] = lw;
             }
-            wn_mfma_fence(gl);
             wn_u4 oh[2], ol[2];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -370,7 +369,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                     buf_st4<WN_L_ST_AUX>(oh[s2], ro, vo_out + 256 * e, (4 * s2) * RS16);
                     buf_st4<WN_L_ST_AUX>(ol[s2], ro, vo_out + 256 * e, (8 + 4 * s2) * RS16);
                 }
-                wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
             } else {
                 // ---- flow head on this column block (same arithmetic as iaf_head_c_kernel) ----
                 f4 hacc[4];
@@ -388,7 +386,6 @@ __global__ __launch_bounds__(W2 ? 512 : 256, ((HN == 1 && !W2) || NOPF) ? 2 : 1)
                         bh[i] = hw;
                         bl[i] = lw;
                     }
-                    wn_mfma_fence(bl);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         hacc[mb] = mfma3(PHl[((ks * 4 + mb) * 2 + 0) * 64], PHl[((ks * 4 + mb) * 2 + 1) * 64], bh, bl, hacc[mb]);
@@ -680,7 +677,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                      [&](int ks) { if (!FIRST) load_bc(k + 1, ks, pred); });
             wn_u4 oh[2], ol[2];
             pair_epilogue(LA, acc, th, tl, oh, ol, amax);
-            wn_mfma_fence(ol[0], ol[1]);            // layer B contracts over them straight from these registers
             // ---- layer B ----
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb] = cb[mb];
@@ -702,7 +698,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void iaf_pair_c_kernel(
                     buf_st4<WN_L_ST_AUX>(qh[s2], ro, vo_out, (4 * s2) * RS16);
                     buf_st4<WN_L_ST_AUX>(ql[s2], ro, vo_out, (8 + 4 * s2) * RS16);
                 }
-                wn_store_fence(qh[0], ql[0], qh[1], ql[1]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) { ph[s2] = oh[s2]; pl[s2] = ol[s2]; }
@@ -811,7 +806,6 @@ __global__ __launch_bounds__(256, 2) void iaf_head_c_kernel(
                     bh[i] = hw;
                     bl[i] = lw;
                 }
-                wn_mfma_fence(bl);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb][e] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[mb][e]);
             }

@@ -33,8 +33,12 @@
 #include "wn_mfma_h.h"
 #include "wn_iaf_c.h"
 
-#ifndef GK_ABL
-#define GK_ABL 0      // TEMPORARY measurement switch (bits): results are WRONG when set
+#ifdef GK_STAMPS
+// TEMPORARY timeline aid: s_memtime stamps of waves 0 and 11 of a few workgroups (dev builds only)
+__device__ unsigned long long gk_stamps[8 * 2 * 32];
+#define GK_STAMP(k) do { if (stamp_slot >= 0 && (k) < 30) stamp_base[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GK_STAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -123,6 +127,14 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
     const int RS16 = (int)A.RS * 16;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
     float amax = 0.f;
+#ifdef GK_STAMPS
+    // workgroups 0, 37, 74, ... (8 of them), waves 0 and 11
+    const int stamp_slot = (blockIdx.x % 31 == 0 && blockIdx.x / 31 < 8 && (wave == 0 || wave == GK_WAVES - 1) && lane == 0)
+                               ? (int)(blockIdx.x / 31) * 2 + (wave ? 1 : 0) : -1;
+    unsigned long long* stamp_base = gk_stamps + (stamp_slot < 0 ? 0 : stamp_slot) * 32;
+    if (stamp_slot >= 0) { stamp_base[30] = __builtin_amdgcn_s_memrealtime(); stamp_base[29] = 0; }
+    GK_STAMP(0);
+#endif
 
     // zero block -1 of both planes (never written afterwards)
     if (threadIdx.x < 256)
@@ -227,23 +239,28 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                 for (int mb = 0; mb < 4; ++mb)      // blocks outside the row block fall outside the descriptor: zeros
                     cn[e][mb] = buf_ldf4(rc, (cblk0 + blk_of(e)) * 4096 + lane * 16, mb * 1024);
         };
-        load_c(A.L[0].C);
-        // A K loop needs the segment and the fragment image, not the hoisted tile (added behind it): the eight C loads
-        // are the youngest requests of the wave and vmcnt retires in order, so they stay in flight across the barrier
-        // and the first K loop -- 96 of the 249 KB a workgroup asks for in its prologue, when every CU asks at once.
-        g_dma_wait_but<4 * GK_HN>();
+        GK_STAMP(1);
+        // (the hoisted tile of a layer is requested in front of its K loop, below: 96 of the 249 KB a workgroup would
+        // otherwise ask for in this burst, when every CU asks at once)
+        g_dma_wait();
+        GK_STAMP(2);
         __syncthreads();
+        GK_STAMP(3);
 
         for (int j = 0; j < A.nl; ++j) {
             const bool fin = j + 1 == A.nl;
             const int d = A.L[j].d;
             const bool run = blk_of(GK_HN - 1) >= A.L[j].first;   // any block of this wave still needed from this layer
+            // the layer's hoisted tile is requested HERE, in front of its K loop: the vector-memory port is idle during the
+            // K loop and the tile has all of it to arrive; at the start of the epilogue (where it used to be requested,
+            // together with the next image) the 13 requests of every wave queued behind each other for 1.3 - 2.6 k cycles
+            load_c(A.L[j].C);
             f4 acc[GK_HN][4];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[e][mb] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (run && !(GK_ABL & 8)) {
+            if (run) {
                 // B operands: column 16 i + n - shift of the layer input, one 16-byte LDS word per (tap, half, plane)
                 int ba[GK_HN][3];
 #pragma unroll
@@ -266,46 +283,40 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         const wn_u4 bh = *reinterpret_cast<const wn_u4*>(lds + ba[e][ks >> 1] + (ks & 1) * 1024);
                         const wn_u4 bl = *reinterpret_cast<const wn_u4*>(lds + GK_PLANE + ba[e][ks >> 1] + (ks & 1) * 1024);
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) {
-                            if (GK_ABL & 16) acc[e][mb] = mfma_h(a[mb][0], bh, acc[e][mb]);
-                            else acc[e][mb] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[e][mb]);
-                        }
+                        for (int mb = 0; mb < 4; ++mb) acc[e][mb] = mfma3(a[mb][0], a[mb][1], bh, bl, acc[e][mb]);
                     }
                 }
             }
+            GK_STAMP(4 + 5 * j);
             g_dma_wait();                                  // the layer's tail image and its C tile
             __syncthreads();                               // every wave has read the layer input and the fragments
-            if (!fin) { if (!(GK_ABL & 1)) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane); }
+            GK_STAMP(6 + 5 * j);
+            if (!fin) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
             else if (LAST) {
                 g_dma_image(A.whead, lds_base + GK_A_OFF, HC_A_WORDS, wave, lane);
                 g_dma_image(A.whead + IAF_PH_FLOATS, lds_base + GK_A_OFF + HC_A_WORDS * 4, HC_TAIL_WORDS, wave, lane);
             }
-            // the hoisted term joins behind the K loop, and its registers take the next layer's (or the head's) tile: a
-            // whole epilogue and K loop to land in
+            // the hoisted term joins behind the K loop (its registers then take the head's tile in a flow's last group)
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[e][mb] += cn[e][mb];
-            if (!fin) { if (!(GK_ABL & 2)) load_c(A.L[j + 1].C); }
-            else if (LAST) load_c(A.Ch);
+            if (fin && LAST) load_c(A.Ch);
+            GK_STAMP(5 + 5 * j);                           // next image and next hoisted tile requested
             W.inv_m = tailf[IAF_PR_FLOATS + 128];
             W.inv_r = tailf[IAF_PR_FLOATS + 129];
-#pragma unroll
-            for (int e = 0; e < GK_HN; ++e) {
-                const int i = blk_of(e);
-                if (i < A.L[j].first || !active(i)) continue;          // not needed / outside the utterance (stays zero)
-                char* blk = lds + (i + 1) * GK_BLK_BYTES + own;
-                wn_u4 lh[2], ll[2], oh[2], ol[2];
+            // epilogue of one block: gate, residual 1x1, skip; in-place update of the block (or the group's output)
+            auto epi_load = [&](int e, wn_u4 (&lh)[2], wn_u4 (&ll)[2]) {
+                char* blk = lds + (blk_of(e) + 1) * GK_BLK_BYTES + own;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     lh[s] = *reinterpret_cast<const wn_u4*>(blk + s * 1024);
                     ll[s] = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE + s * 1024);
                 }
-                if (GK_ABL & 4) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) { oh[s] = lh[s] ^ __builtin_bit_cast(wn_u4, acc[e][s]); ol[s] = ll[s] ^ __builtin_bit_cast(wn_u4, acc[e][2 + s]); }
-                } else
-                pair_epilogue(W, acc[e], lh, ll, oh, ol, amax);
+            };
+            auto epi_store = [&](int e, const wn_u4 (&oh)[2], const wn_u4 (&ol)[2]) {
+                const int i = blk_of(e);
+                char* blk = lds + (i + 1) * GK_BLK_BYTES + own;
                 if (!fin || LAST) {                                    // (LAST: the head below reads its input from here)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -324,14 +335,28 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         buf_st4(oh[s], ro, vo, (4 * s) * RS16);
                         buf_st4(ol[s], ro, vo, (8 + 4 * s) * RS16);
                     }
-                    wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
+                }
+            };
+            bool on[GK_HN];
+#pragma unroll
+            for (int e = 0; e < GK_HN; ++e) on[e] = blk_of(e) >= A.L[j].first && active(blk_of(e));
+            {
+#pragma unroll
+                for (int e = 0; e < GK_HN; ++e) {
+                    if (!on[e]) continue;                                  // not needed / outside the utterance (stays zero)
+                    wn_u4 lh[2], ll[2], oh[2], ol[2];
+                    epi_load(e, lh, ll);
+                    pair_epilogue(W, acc[e], lh, ll, oh, ol, amax);
+                    epi_store(e, oh, ol);
                 }
             }
+            GK_STAMP(7 + 5 * j);
             // this wave's share of the next image has landed (the C loads behind it stay in flight)
-            if (!fin || LAST) g_dma_wait_but<4 * GK_HN>();
+            if (fin && LAST) g_dma_wait_but<4 * GK_HN>();      // the head's tile stays in flight
             else g_dma_wait();
+            GK_STAMP(8 + 5 * j);                           // this wave's pieces of the next image have landed
             __syncthreads();                               // layer output in LDS, next image complete, tail buffer free
-            if (!fin && !(GK_ABL & 1)) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
+            if (!fin) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
         }
 
         if (LAST) {
@@ -363,7 +388,6 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         bh[k] = hw;
                         bl[k] = lw;
                     }
-                    wn_mfma_fence(bl);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         hacc[mb] = mfma3(PHl[((ks * 4 + mb) * 2 + 0) * 64], PHl[((ks * 4 + mb) * 2 + 1) * 64], bh, bl, hacc[mb]);
@@ -396,10 +420,20 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         }
     }
     wn_range_flag(amax, A.status);
+#ifdef GK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp_slot >= 0) { stamp_base[29] = __builtin_amdgcn_s_memtime(); stamp_base[31] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 
 }  // namespace
+
+#ifdef GK_STAMPS
+extern "C" int wn_dbg_gk_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gk_stamps), sizeof(unsigned long long) * 8 * 2 * 32);
+}
+#endif
 
 int wn_iaf_g_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_group_kernel<false, false>),

@@ -217,7 +217,6 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 gh[i] = hw;
                 gl[i] = lw;
             }
-            wn_mfma_fence(gl);
             wn_u4 oh[2], ol[2];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -240,7 +239,6 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
                 buf_st4(oh[s2], ro, vo_out + 16 * e, (4 * s2) * RS16);
                 buf_st4(ol[s2], ro, vo_out + 16 * e, (8 + 4 * s2) * RS16);
             }
-            wn_store_fence(oh[0], ol[0], oh[1], ol[1]);
         }
     }
     wn_range_flag(amax, status);
@@ -340,7 +338,6 @@ __global__ __launch_bounds__(256, 1) void iaf_head_h_kernel(
                         bh[i] = hw;
                         bl[i] = lw;
                     }
-                    wn_mfma_fence(bl);
                 }
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)

@@ -111,21 +111,19 @@ template <int AUX = 0>
 __device__ inline wn_u4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
 }
+// 16-byte store of a residual-stream word.  A wide store reads its data VGPRs some cycles after it issues; the ISA manual
+// asks for a wait state before a VALU instruction overwrites them EXCEPT for buffer stores with an SGPR soffset, hipcc's
+// hazard recognizer implements that exemption, and on gfx950 it does not hold: the group kernel lost quads of lanes of
+// `buffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen` to the `v_max_f32 v48, ...` the register allocator and the
+// scheduler had put right behind it (nondeterministic, nearly every call; profiles/r03_store_hazard.txt).  The asm
+// statement behind the store READS the stored registers -- they stay allocated up to it, nothing scheduled in between can
+// write them -- and holds two wait states.  It lives HERE, in the one helper every such store goes through (round 3 had
+// it at the call sites: the next new call site would have been unguarded).  scripts/audit_store_hazard.py (run by
+// tests/test_host.py) still reads the compiler's assembly of every kernel for the pattern.
 template <int AUX = 0>
 __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
-}
-// Ends a run of 16-byte stores of the words a .. d.  A wide store reads its data VGPRs some cycles after it issues; the
-// ISA manual asks for a wait state before a VALU instruction overwrites them EXCEPT for buffer stores with an SGPR
-// soffset, hipcc's hazard recognizer implements that exemption, and on gfx950 it does not hold: the group kernel lost
-// quads of lanes of `buffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen` to the `v_max_f32 v48, ...` the register
-// allocator and the scheduler had put right behind it (nondeterministic, nearly every call;
-// profiles/r03_store_hazard.txt).  The statement below READS the stored registers, so they stay allocated up to it
-// -- nothing scheduled between the stores and the statement can write them -- and its two wait states separate the
-// last store from whatever reuses them afterwards.  scripts/audit_store_hazard.py (run by tests/test_host.py)
-// checks the compiler's assembly of every kernel for the pattern.
-__device__ inline void wn_store_fence(const wn_u4& a, const wn_u4& b, const wn_u4& c, const wn_u4& d) {
-    asm volatile("s_nop 1" ::"v"(a), "v"(b), "v"(c), "v"(d));
+    asm volatile("s_nop 1" ::"v"(v));
 }
 
 
@@ -153,8 +151,6 @@ __device__ inline void first_layer_operands(const float (&xv)[5], long long t, i
                 bc[2 * tap + s].l[0][i] = lw;
             }
         }
-#pragma unroll
-    for (int k = 0; k < 6; k += 2) wn_mfma_fence(bc[k].l[0], bc[k + 1].l[0]);     // operands of the K loop that follows
 }
 // stage (w0, w1, w2, b) per channel from the start-conv block w[3][64] | b[64]
 __device__ inline void stage_start_weights(const float* __restrict__ wb, f4* wq) {

@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
                 wn_split_pair(fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f), h3, l3);
                 vh[e] = (wn_u4){h0, h1, h2, h3};
                 vl[e] = (wn_u4){l0, l1, l2, l3};
-                wn_mfma_fence(vl[e]);
             }
         }
     };

@@ -6,15 +6,16 @@ manual asks for one wait state before a VALU instruction overwrites them and exe
 SOFFSET is an SGPR; LLVM's hazard recognizer implements that exemption (GCNHazardRecognizer::
 createsVALUHazard).  On gfx950 the exemption does not hold: round 3 lost quads of lanes of a
 `buffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen` to the `v_max_f32 v48, ...` right behind it
-(profiles/r03_store_hazard.txt).  The kernels therefore end every run of such stores with wn_store_fence()
-(wn_mfma_h.h); this script disassembles nothing, it reads the compiler's own .s and fails if a wide store
+(profiles/r03_store_hazard.txt).  The one store helper of the residual stream (buf_st4, wn_mfma_h.h) therefore holds two
+wait states behind every such store, with the stored registers kept alive up to them; this script is the second line:
+it disassembles nothing, it reads the compiler's own .s and fails if a wide store
 is followed within WINDOW instruction slots by a VALU write of its data registers.
 
 Second rule, same mechanism: an MFMA that reads a VGPR with fewer than two wait states behind the VALU instruction that
-wrote it gets the OLD register content (scripts/ubench/valu_to_mfma.hip).  hipcc pads its own VALU -> MFMA pairs, but the
-lo words of the split-fp16 codec come out of v_fma_mix* instructions inside asm statements, which it cannot see into;
-every operand built from them passes through wn_mfma_fence() (wn_codec.h).  The audit flags any asm VALU result that an
-MFMA reads earlier than that.
+wrote it gets the OLD register content (scripts/ubench/valu_to_mfma.hip).  hipcc pads its own VALU -> MFMA pairs but
+cannot see into an asm statement.  Round 3's split codec was such asm and needed a fence at every use site; since round
+4 the split is plain C++ (wn_codec.h) and no asm result feeds an MFMA any more.  The audit still flags any asm VALU
+result that an MFMA reads earlier than two wait states behind it, should one come back.
 
     python scripts/audit_store_hazard.py            # compiles csrc/*.hip with -save-temps into a temp dir
 """

@@ -74,14 +74,14 @@ def asm_block(body, prio=None):
     pre = init[:]
     if prio is not None:
         pre.append(f"s_setprio {prio}")
-    pre += ["s_barrier", "s_memtime %0", "s_waitcnt lgkmcnt(0)", "L_loop_%=:"]
+    pre += ["s_barrier", "s_memrealtime %3", "s_memtime %0", "s_waitcnt lgkmcnt(0)", "L_loop_%=:"]
     post = ["s_sub_u32 %2, %2, 1", "s_cmp_lg_u32 %2, 0", "s_cbranch_scc1 L_loop_%=", "s_nop 7", "s_nop 7", "s_memtime %1",
-            "s_waitcnt lgkmcnt(0)"]
+            "s_memrealtime %4", "s_waitcnt lgkmcnt(0)"]
     if prio is not None:
         post.append("s_setprio 0")
     text = "\\n\\t".join(pre + body + post)
     clob = ", ".join(f'"v{i}"' for i in range(0, 120))
-    return (f'asm volatile("{text}"\n                 : "=&s"(t0), "=&s"(t1), "+s"(it) : : {clob}, "scc", "memory");')
+    return (f'asm volatile("{text}"\n                 : "=&s"(t0), "=&s"(t1), "+s"(it), "=&s"(r0), "=&s"(r1) : : {clob}, "scc", "memory");')
 
 
 KERNELS = []   # (name, nm, nv, m_lines, v_lines, mfma per iter, fillers per M iter, fillers per V iter, prio_m, prio_v, descr)
@@ -132,13 +132,13 @@ def emit(out):
     w("// GENERATED by scripts/ubench/gen_issue_overlap.py -- do not edit.  (dev tool, not product)\n")
     w("// Hand-placed MFMA / VALU issue streams on gfx950: see the generator's docstring.\n")
     w("#include <hip/hip_runtime.h>\n#include <cstdio>\n#include <cstring>\n#include <string>\n#include <vector>\n\n")
-    w("struct Rec { unsigned long long t0, t1; unsigned hwid, role; };\n\n")
+    w("struct Rec { unsigned long long t0, t1, r0, r1; unsigned hwid, role; };\n\n")
     for k in KERNELS:
         nt = 64 * (k["nm"] + k["nv"])
         w(f"// {k['name']}: M waves {k['nm']}, V waves {k['nv']}\n")
         w(f"extern \"C\" __global__ __launch_bounds__({nt}) void {k['name']}(Rec* out, int iters_m, int iters_v) {{\n")
         w("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);\n")
-        w("    unsigned long long t0 = 0, t1 = 0;\n    unsigned role;\n    int it;\n")
+        w("    unsigned long long t0 = 0, t1 = 0, r0 = 0, r1 = 0;\n    unsigned role;\n    int it;\n")
         if k["nm"] and k["nv"]:
             w(f"    if (wave < {k['nm']}) {{\n        role = 0; it = iters_m;\n        ")
             w(asm_block(k["ml"], k["prio_m"]))
@@ -154,7 +154,7 @@ def emit(out):
             w(asm_block(k["vl"], k["prio_v"]))
             w("\n")
         w("    unsigned hwid;\n    asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hwid));\n")
-        w(f"    if ((threadIdx.x & 63) == 0) out[blockIdx.x * {k['nm'] + k['nv']} + wave] = Rec{{t0, t1, hwid, role}};\n}}\n\n")
+        w(f"    if ((threadIdx.x & 63) == 0) out[blockIdx.x * {k['nm'] + k['nv']} + wave] = Rec{{t0, t1, r0, r1, hwid, role}};\n}}\n\n")
     w("struct K { const char* name; void (*fn)(Rec*, int, int); int nm, nv, u, fm, fv, pipe; };\n")
     w("static const K kernels[] = {\n")
     for k in KERNELS:
@@ -188,18 +188,26 @@ int main(int argc, char** argv) {
             }
             hipMemcpy(h.data(), d, 256 * (k.nm + k.nv) * sizeof(Rec), hipMemcpyDeviceToHost);
             // workgroup 37 (any): per wave cycles; averages over all workgroups
-            double sm = 0, sv = 0;
+            double sm = 0, sv = 0, mn[2] = {1e30, 1e30}, mx[2] = {0, 0}, ticks = 0, real = 0;
             int cm = 0, cv = 0;
             for (int b = 0; b < 256; ++b)
                 for (int w = 0; w < k.nm + k.nv; ++w) {
                     const Rec& r = h[b * (k.nm + k.nv) + w];
                     const double c = (double)(r.t1 - r.t0);
                     if (r.role == 0) { sm += c / im; ++cm; } else { sv += c / iv; ++cv; }
+                    const double per = c / (r.role == 0 ? im : iv);
+                    if (per < mn[r.role]) mn[r.role] = per;
+                    if (per > mx[r.role]) mx[r.role] = per;
+                    ticks += c;
+                    real += (double)(r.r1 - r.r0);
                 }
             printf("%-28s %2d/%-2d u=%2d fm=%3d fv=%2d iters %5d/%-5d |", k.name, k.nm, k.nv, k.u, k.fm, k.fv, im, iv);
             if (cm) printf(" M %8.1f cyc/iter = %6.2f cyc/MFMA (pipe %d)", sm / cm, sm / cm / k.u, k.pipe);
             if (cm && k.fm) printf(" [%5.2f cyc/instr]", sm / cm / (k.u + k.fm));
             if (cv) printf(" | V %8.1f cyc/iter = %5.2f cyc/filler", sv / cv, sv / cv / k.fv);
+            if (cm) printf(" | M min %.1f max %.1f", mn[0], mx[0]);
+            if (cv) printf(" | V min %.1f max %.1f", mn[1], mx[1]);
+            printf(" | s_memtime %.3f GHz (vs 100 MHz s_memrealtime)", real > 0 ? ticks / real * 0.1 : 0.0);
             // SIMD placement of workgroup 37
             printf(" | simd:");
             for (int w = 0; w < k.nm + k.nv; ++w) printf("%u", (h[37 * (k.nm + k.nv) + w].hwid >> 4) & 3);
