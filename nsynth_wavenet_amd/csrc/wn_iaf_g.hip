@@ -57,6 +57,8 @@ static_assert(GK_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
 static_assert(GK_S_OFF % 16 == 0 && GK_T_OFF % 16 == 0, "");
 static_assert(HC_LDS_WORDS <= LC_A_WORDS, "the head image takes over the fragment buffer");
 constexpr int GK_MAXL = 5;
+constexpr int GK_ST = LC_A_WORDS / 4 / GK_THREADS;           // 16-byte pieces of the next image a thread stages
+static_assert(GK_ST * GK_THREADS * 4 == LC_A_WORDS && (LC_TAIL_WORDS + 3) / 4 <= GK_THREADS && HC_TAIL_WORDS <= LC_TAIL_WORDS && HC_A_WORDS <= LC_A_WORDS, "staging shares");
 constexpr int GK_DEC = 32;                                     // decimation of a "dec" group
 constexpr int GK_PADJ = 64;                                    // zero columns in front of every residue row of the DL layout
 
@@ -186,6 +188,18 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         // time of column n of LDS block i
         auto time_of = [&](int i) -> int { return A.in_dec ? r + GK_DEC * (16 * (blk0 + i) + n) : 16 * (blk0 + i) + n; };
 
+        // The accumulators of a layer START from its hoisted tile: requested as soon as the previous layer's epilogue
+        // arithmetic has released the registers (layer 0: here), one 16-byte load per row block.
+        f4 acc[GK_HN][4];
+        auto load_c = [&](const float* Cbase) {
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(Cbase + (size_t)b * A.c_bstride), 0, A.nb_tot * 4096, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < GK_HN; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)      // blocks outside the row block fall outside the descriptor: zeros
+                    acc[e][mb] = buf_ldf4(rc, (cblk0 + blk_of(e)) * 4096 + lane * 16, mb * 1024);
+        };
         // ---- prologue: l segment, first layer's image, first C tiles ----
         if (FIRST) {
             // l0 = start_conv(shift_right(x)) (parallel_wavenet.py:222-225), zero left of the utterance
@@ -229,20 +243,11 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         }
         g_dma_image(A.L[0].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
         g_dma_image(A.L[0].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
-        f4 cn[GK_HN][4];
-        auto load_c = [&](const float* Cbase) {
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(Cbase + (size_t)b * A.c_bstride), 0, A.nb_tot * 4096, 0x00020000);
-#pragma unroll
-            for (int e = 0; e < GK_HN; ++e)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)      // blocks outside the row block fall outside the descriptor: zeros
-                    cn[e][mb] = buf_ldf4(rc, (cblk0 + blk_of(e)) * 4096 + lane * 16, mb * 1024);
-        };
+        load_c(A.L[0].C);
         GK_STAMP(1);
-        // (the hoisted tile of a layer is requested in front of its K loop, below: 96 of the 249 KB a workgroup would
-        // otherwise ask for in this burst, when every CU asks at once)
-        g_dma_wait();
+        // the segment and the first image have landed (LDS-DMA the compiler does not track: an explicit wait); the eight tile
+        // loads are the youngest requests of the wave and vmcnt retires in order, so they stay in flight across the barrier
+        g_dma_wait_but<4 * GK_HN>();
         GK_STAMP(2);
         __syncthreads();
         GK_STAMP(3);
@@ -251,15 +256,36 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             const bool fin = j + 1 == A.nl;
             const int d = A.L[j].d;
             const bool run = blk_of(GK_HN - 1) >= A.L[j].first;   // any block of this wave still needed from this layer
-            // the layer's hoisted tile is requested HERE, in front of its K loop: the vector-memory port is idle during the
-            // K loop and the tile has all of it to arrive; at the start of the epilogue (where it used to be requested,
-            // together with the next image) the 13 requests of every wave queued behind each other for 1.3 - 2.6 k cycles
-            load_c(A.L[j].C);
-            f4 acc[GK_HN][4];
+            // ---- the NEXT image (the next layer's fragments and tail, or the head's) is requested in front of the K loop,
+            // where the vector-memory port is idle, and staged through registers: it cannot go to LDS before the last K loop
+            // of this layer has read the current one, and an LDS-DMA issued at that point would put its 2-3 k cycles of
+            // latency between the two barriers below
+            const unsigned* s_img = nullptr;
+            const unsigned* s_tail = nullptr;
+            int n_img = 0, n_tail = 0;
+            unsigned d_tail = GK_T_OFF;
+            if (!fin) {
+                s_img = A.L[j + 1].w;
+                s_tail = s_img + IAF_P_FLOATS;
+                n_img = LC_A_WORDS / 4;
+                n_tail = (LC_TAIL_WORDS + 3) / 4;
+            } else if (LAST) {
+                s_img = A.whead;
+                s_tail = s_img + IAF_PH_FLOATS;
+                n_img = HC_A_WORDS / 4;
+                n_tail = (HC_TAIL_WORDS + 3) / 4;
+                d_tail = GK_A_OFF + HC_A_WORDS * 4;
+            }
+            wn_u4 st[GK_ST], stt = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int e = 0; e < GK_HN; ++e)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[e][mb] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < GK_ST; ++i) {
+                const int idx = i * GK_THREADS + (int)threadIdx.x;
+                st[i] = (wn_u4){0u, 0u, 0u, 0u};
+                if (idx < n_img) st[i] = *reinterpret_cast<const wn_u4*>(s_img + (size_t)idx * 4);
+            }
+            if ((int)threadIdx.x < n_tail) stt = *reinterpret_cast<const wn_u4*>(s_tail + (size_t)threadIdx.x * 4);
+
+            // ---- K loop: dilated conv of this wave's blocks on top of the hoisted tile ----
             if (run) {
                 // B operands: column 16 i + n - shift of the layer input, one 16-byte LDS word per (tap, half, plane)
                 int ba[GK_HN][3];
@@ -288,75 +314,85 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                 }
             }
             GK_STAMP(4 + 5 * j);
-            g_dma_wait();                                  // the layer's tail image and its C tile
-            __syncthreads();                               // every wave has read the layer input and the fragments
-            GK_STAMP(6 + 5 * j);
-            if (!fin) g_dma_image(A.L[j + 1].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
-            else if (LAST) {
-                g_dma_image(A.whead, lds_base + GK_A_OFF, HC_A_WORDS, wave, lane);
-                g_dma_image(A.whead + IAF_PH_FLOATS, lds_base + GK_A_OFF + HC_A_WORDS * 4, HC_TAIL_WORDS, wave, lane);
-            }
-            // the hoisted term joins behind the K loop (its registers then take the head's tile in a flow's last group)
-#pragma unroll
-            for (int e = 0; e < GK_HN; ++e)
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[e][mb] += cn[e][mb];
-            if (fin && LAST) load_c(A.Ch);
-            GK_STAMP(5 + 5 * j);                           // next image and next hoisted tile requested
-            W.inv_m = tailf[IAF_PR_FLOATS + 128];
-            W.inv_r = tailf[IAF_PR_FLOATS + 129];
-            // epilogue of one block: gate, residual 1x1, skip; in-place update of the block (or the group's output)
-            auto epi_load = [&](int e, wn_u4 (&lh)[2], wn_u4 (&ll)[2]) {
-                char* blk = lds + (blk_of(e) + 1) * GK_BLK_BYTES + own;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    lh[s] = *reinterpret_cast<const wn_u4*>(blk + s * 1024);
-                    ll[s] = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE + s * 1024);
-                }
-            };
-            auto epi_store = [&](int e, const wn_u4 (&oh)[2], const wn_u4 (&ol)[2]) {
-                const int i = blk_of(e);
-                char* blk = lds + (i + 1) * GK_BLK_BYTES + own;
-                if (!fin || LAST) {                                    // (LAST: the head below reads its input from here)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        *reinterpret_cast<wn_u4*>(blk + s * 1024) = oh[s];
-                        *reinterpret_cast<wn_u4*>(blk + GK_PLANE + s * 1024) = ol[s];
-                    }
-                } else {
-                    // the group's output: natural order, or scattered once into the DL layout of the next (decimated) group
-                    const int t = time_of(i);
-                    const int col = A.out_dec ? (t & (GK_DEC - 1)) * A.RJ + GK_PADJ + (t >> 5) : IAF_LP + t;
-                    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(A.lout + (size_t)b * IAF_W * A.RS), 0, IAF_W * (int)A.RS * 4, 0x00020000);
-                    const int vo = q * RS16 + col * 16;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        buf_st4(oh[s], ro, vo, (4 * s) * RS16);
-                        buf_st4(ol[s], ro, vo, (8 + 4 * s) * RS16);
-                    }
-                }
-            };
             bool on[GK_HN];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) on[e] = blk_of(e) >= A.L[j].first && active(blk_of(e));
-            {
+            wn_u4 oh[GK_HN][2], ol[GK_HN][2];
+            // Epilogue arithmetic of the wave's blocks.  Nothing is written in place here -- other waves' K loops may still
+            // read this layer's input -- the outputs wait in registers.  The accumulators are free afterwards: the next
+            // layer's (or the head's) hoisted tile is requested into them.
+            auto epi_math = [&]() {
+                W.inv_m = tailf[IAF_PR_FLOATS + 128];
+                W.inv_r = tailf[IAF_PR_FLOATS + 129];
 #pragma unroll
                 for (int e = 0; e < GK_HN; ++e) {
-                    if (!on[e]) continue;                                  // not needed / outside the utterance (stays zero)
-                    wn_u4 lh[2], ll[2], oh[2], ol[2];
-                    epi_load(e, lh, ll);
-                    pair_epilogue(W, acc[e], lh, ll, oh, ol, amax);
-                    epi_store(e, oh, ol);
+                    if (!on[e]) continue;                      // not needed / outside the utterance (stays zero)
+                    const char* blk = lds + (blk_of(e) + 1) * GK_BLK_BYTES + own;
+                    wn_u4 lh[2], ll[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        lh[s2] = *reinterpret_cast<const wn_u4*>(blk + s2 * 1024);
+                        ll[s2] = *reinterpret_cast<const wn_u4*>(blk + GK_PLANE + s2 * 1024);
+                    }
+                    pair_epilogue(W, acc[e], lh, ll, oh[e], ol[e], amax);
+                }
+                if (!fin) load_c(A.L[j + 1].C);
+                else if (LAST) load_c(A.Ch);
+            };
+            // The waves of a SIMD get the matrix pipe in the order of their age, so a wave that runs its epilogue arithmetic
+            // STRAIGHT behind its own K loop -- no barrier in between -- does it in the shadow of the younger waves' MFMAs
+            // (profiles/r04_issue_overlap_ubench.txt: VALU work issues beside a running MFMA on gfx950, within a wave and
+            // between waves; r04_group_kernel_stamps.txt: the oldest wave of a SIMD is through its K loop after 4.3 k cycles,
+            // the youngest after 8.5 k).  Only the youngest wave's arithmetic is left exposed.  (Putting the barrier behind
+            // the K loops instead, so that the older waves write their outputs while the youngest still computes, was
+            // measured much slower -- 70 against 58 us per launch: the write burst starves the youngest waves' LDS reads.)
+            epi_math();
+            if (fin && !LAST) {
+                // the group's output leaves from the registers: natural order, or scattered once into the DL layout of the
+                // next (decimated) group.  Nothing of this layer goes back to LDS.
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(A.lout + (size_t)b * IAF_W * A.RS), 0, IAF_W * (int)A.RS * 4, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < GK_HN; ++e) {
+                    if (!on[e]) continue;
+                    const int t = time_of(blk_of(e));
+                    const int col = A.out_dec ? (t & (GK_DEC - 1)) * A.RJ + GK_PADJ + (t >> 5) : IAF_LP + t;
+                    const int vo = q * RS16 + col * 16;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        buf_st4(oh[e][s2], ro, vo, (4 * s2) * RS16);
+                        buf_st4(ol[e][s2], ro, vo, (8 + 4 * s2) * RS16);
+                    }
+                }
+                GK_STAMP(5 + 5 * j);
+                continue;
+            }
+            GK_STAMP(5 + 5 * j);
+            __syncthreads();                               // every K loop has read this layer's input and fragments, every
+                                                           // epilogue this layer's tail
+            GK_STAMP(6 + 5 * j);
+            // in-place update of the wave's blocks (LAST: the head below reads its input from here) ...
+#pragma unroll
+            for (int e = 0; e < GK_HN; ++e) {
+                if (!on[e]) continue;
+                char* blk = lds + (blk_of(e) + 1) * GK_BLK_BYTES + own;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    *reinterpret_cast<wn_u4*>(blk + s2 * 1024) = oh[e][s2];
+                    *reinterpret_cast<wn_u4*>(blk + GK_PLANE + s2 * 1024) = ol[e][s2];
                 }
             }
+            // ... the staged fragments (only K loops read that buffer: all done) ...
+#pragma unroll
+            for (int i = 0; i < GK_ST; ++i) {
+                const int idx = i * GK_THREADS + (int)threadIdx.x;
+                if (idx < n_img) *reinterpret_cast<wn_u4*>(lds + GK_A_OFF + idx * 16) = st[i];
+            }
+            // ... and the staged tail
+            if ((int)threadIdx.x < n_tail) *reinterpret_cast<wn_u4*>(lds + d_tail + threadIdx.x * 16) = stt;
             GK_STAMP(7 + 5 * j);
-            // this wave's share of the next image has landed (the C loads behind it stay in flight)
-            if (fin && LAST) g_dma_wait_but<4 * GK_HN>();      // the head's tile stays in flight
-            else g_dma_wait();
-            GK_STAMP(8 + 5 * j);                           // this wave's pieces of the next image have landed
-            __syncthreads();                               // layer output in LDS, next image complete, tail buffer free
-            if (!fin) g_dma_image(A.L[j + 1].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
+            __syncthreads();                               // layer output and next image in LDS
+            GK_STAMP(8 + 5 * j);
         }
 
         if (LAST) {
@@ -373,7 +409,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                 if (i < A.hb || !active(i)) continue;
                 f4 hacc[4];
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) hacc[mb] = cn[e][mb];
+                for (int mb = 0; mb < 4; ++mb) hacc[mb] = acc[e][mb];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     // the group's output block, written in place by this lane in the last layer's epilogue

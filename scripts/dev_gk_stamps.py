@@ -22,7 +22,7 @@ assert lib.wn_dbg_gk_stamps(buf) == 0
 a = np.array(buf[:], dtype=np.uint64).reshape(8, 2, 32).astype(np.int64)
 names = ['entry', 'prologue issued', 'prologue landed', 'barrier']
 for j in range(5):
-    names += ['L%d K done' % j, 'L%d next image+C requested' % j, 'L%d barrier after K' % j, 'L%d epilogue math done' % j, 'L%d own image pieces landed' % j]
+    names += ['L%d K done' % j, 'L%d epilogue math done' % j, 'L%d barrier 1' % j, 'L%d outputs + image written' % j, 'L%d barrier 2' % j]
 print('# %s group, last launch of the call; cycles since entry (s_memtime); rows = stamps, columns = workgroup/wave' % which)
 r0 = a[:, :, 30].min()
 print('%-28s' % 'start (us after first, realtime)', ' '.join('%8.2f' % ((a[g, wv, 30] - r0) / 100.0) for g in range(8) for wv in range(2)))

@@ -78,6 +78,39 @@ def test_config0_student_on_the_fixture_shaped_utterance():
     assert np.abs(o['x'] - ref_x).max() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('batch', [2, 3])
+def test_layer_groups_at_two_and_three_full_size_utterances(batch):
+    """BASELINE configs[1] length (F = 384 -> T = 76 800) at the other batch sizes the launch policy gives to the
+    layer-group kernel (wn_iaf_use_groups: up to three 4.8 s utterances per GPU): the group form against the independent
+    torch-CPU implementation on every sample of every utterance, the per-layer form on the same call, and row
+    independence (utterance b of the batched call == the same utterance alone, bit for bit)."""
+    import torch
+    from oracle import wavenet_np as O
+    from oracle.torch_ref import StudentRef
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    F, T = 384, 76800
+    assert O.iaf_length(F, hp) == T
+    mel = np.random.RandomState(12345 + batch).uniform(0, 1, [batch, F, 80]).astype(np.float32)
+    noise = O.logistic_from_uniform(np.random.RandomState(12346 + batch).uniform(1e-5, 1 - 1e-5, [batch, T]))
+    eng = Engine(cfgd).load_weights(w)
+    assert eng.iaf_cond_hoisted(batch, F) and eng.iaf_layer_groups(batch, F)        # the policy picks the group kernel here
+    out = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot', 'idx'))
+    x = _np(out['x']).astype(np.float64)
+    m, sc = _np(out['mean_tot']).astype(np.float64), _np(out['scale_tot']).astype(np.float64)
+    assert x.shape == (batch, T) and np.isfinite(x).all() and np.all(sc > 0)
+    scale = max(1.0, np.abs(x).max())
+    assert np.abs(x - (noise.astype(np.float64) * sc + m)).max() <= 1e-6 * scale                      # K2
+    ref = StudentRef(w, hp).feed_forward(mel, noise)
+    assert np.abs(x - ref['x'].astype(np.float64)).max() <= 2e-5 * scale
+    assert np.abs(sc - ref['scale_tot'].astype(np.float64)).max() <= 2e-5 * max(1.0, float(ref['scale_tot'].max()))
+    one = eng.iaf_generate(mel[batch - 1:], noise[batch - 1:], want=('x',))
+    assert torch.equal(one['x'][0], out['x'][batch - 1])
+    eng.close()
+
+
 def test_config0_fastgen_on_the_fixture_shaped_utterance():
     """wavenet_mol.json as shipped: wav -> device mel -> fastgen.encode (F*200 = 154 600 conditioning steps),
     K1 on a 2 048-step prefix (incremental step == full-sequence teacher == float64 oracle), then the free-running
