@@ -46,21 +46,26 @@ PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 BARRIER_KW = {}
 RED_DEV = None
-PROFILE_ROUND = 'r03'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
+PROFILE_ROUND = 'r04'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
 DOMINANT_KERNEL = 'iaf_group_kernel'    # layer groups at one / two utterances; 'iaf_layer_c_kernel' when every layer is a launch
 GROUP_LAYERS = 5                       # residual layers per launch of the group kernel (one half of a dilation cycle)
-# one 16-sample block of one residual layer on a gfx950 SIMD: 84 MFMAs x 16 cycles + the epilogue's 163 VALU x 4 + 32
-# transcendental x 16 cycles -- and the two do NOT overlap on this part (scripts/ubench/mfma_valu_overlap.hip)
-BLOCK_LAYER_PIPE_CYCLES = 84 * 16 + 163 * 4 + 32 * 16
+# One 16-sample block of one residual layer on a gfx950 SIMD: 84 x v_mfma_f32_16x16x32_f16 = 1344 cycles of the matrix
+# pipe.  Round 3 added the epilogue's VALU time to this "floor" on the strength of a micro-benchmark that said the two
+# pipes serialise; round 4's hand-placed streams (scripts/ubench/issue_overlap.hip, profiles/r04_issue_overlap_ubench.txt)
+# show that VALU work DOES issue beside a running MFMA, within a wave and between waves, so the floor of the block is the
+# matrix pipe alone; the epilogue arithmetic beside a saturated pipe needs ~1.7 k cycles of issue and is the longer pole
+# of a perfectly overlapped layer.
+BLOCK_LAYER_MFMA_CYCLES = 84 * 16
 
 
-def pmc_traffic(B, F, precision='f16x3', hoisted=False, kernel=None):
-    """HBM bytes per launch of the dominant layer kernel from the committed rocprofv3 PMC passes
+def pmc_replay(B, F, precision='f16x3', hoisted=False, kernel=None):
+    """(HBM bytes per launch, MFMA utilisation, per-kernel microseconds of a call) of the dominant layer kernel from the committed rocprofv3 PMC passes
     (profiles/r0*_pmc_summary*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
     PMC counters cannot be collected from inside this process, so this is the value of the profiled
     run of the SAME command -- and only when that profile was taken from the kernel sources this
     process runs: a summary carries the hash of csrc/ + include/ (build.source_hash) it was measured
     on; a summary without a hash, or with another one, is stale and gives None."""
+    none = {'traffic': None, 'mfma_util': None, 'kernel_us_per_call': None, 'file': None}
     if precision == 'f32':
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
     elif precision in ('f16x3', 'f16x3-hoisted') and hoisted:
@@ -69,7 +74,7 @@ def pmc_traffic(B, F, precision='f16x3', hoisted=False, kernel=None):
     elif precision in ('f16x3', 'f16x3-fused') and not hoisted:
         names, kernel = [PROFILE_ROUND + '_pmc_summary_f16x3_fused.json'], 'iaf_layer_h_kernel'
     else:
-        return None                      # no PMC summary of its own: never borrow another kernel's figure
+        return none                      # no PMC summary of its own: never borrow another kernel's figure
     have = wbuild.source_hash()
     for name in names:
         try:
@@ -77,10 +82,12 @@ def pmc_traffic(B, F, precision='f16x3', hoisted=False, kernel=None):
                 d = json.load(f)
             w = d['workload']
             if (w['batch_per_gpu'], w['frames']) == (B, F) and d.get('source_hash') == have:
-                return d['kernels'][kernel]['hbm_bytes_per_launch']
+                k = d['kernels'][kernel]
+                return {'traffic': k['hbm_bytes_per_launch'], 'mfma_util': k.get('mfma_util'),
+                        'kernel_us_per_call': d.get('kernel_us_per_call') or None, 'file': 'profiles/' + name}
         except (OSError, KeyError, ValueError):
             pass
-    return None
+    return {'traffic': None, 'mfma_util': None, 'kernel_us_per_call': None, 'file': None}
 
 
 def cpu_baseline(hp_dict, frames, budget_s=25.0):
@@ -161,6 +168,16 @@ def gpu_clocks(index):
         return None
 
 
+def clock_hz_of(clocks):
+    """Shader clock in Hz from a gpu_clocks() record ('(2100Mhz)' style strings), or None."""
+    import re
+    try:
+        m = re.search(r'(\d+(?:\.\d+)?)\s*[Mm][Hh]z', str(clocks['sclk']))
+        return float(m.group(1)) * 1e6 if m else None
+    except (TypeError, KeyError):
+        return None
+
+
 def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp=0):
     """`ramp` + W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
     def step(i):
@@ -201,7 +218,7 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
     return elapsed, layer_ms, layer_launches, wav
 
 
-def roofline_of(eng, B, F, T, layer_ms, layer_launches):
+def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
     """Roofline record of the dominant kernel (the single-layer launches bracketed by HIP events inside the
     library, on the stream they are launched on)."""
     avg_layer_s = layer_ms * 1e-3 / max(layer_launches, 1)
@@ -213,32 +230,39 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
     kernel_key = None
     if hoisted and eng.iaf_layer_groups(B, F):
         # Layer groups: one launch = GROUP_LAYERS residual layers of every sample, the residual stream in LDS; the event
-        # pairs bracket every group launch of the call.  `achieved` counts the bytes such a launch has to move in this
-        # design (read l 256 B, GROUP_LAYERS hoisted terms of 256 B, write l 256 B per sample; halo re-reads excluded);
-        # SURVEY 8(d)'s layer-granular model (1536 B per sample and layer) is given beside it.  The launch is NOT
-        # HBM-bound: a CU spends it in the matrix pipe and the VALU, which do not overlap on gfx950 -- pipe_view.
+        # pairs bracket every group launch of the call.  What binds the launch is the issue of a CU's SIMDs -- the matrix
+        # pipe and, beside it, the VALU -- not HBM: `bound` = "mfma", `achieved` = the fp16 MFMA rate the launch executes
+        # (three MFMAs per product of the split-fp16 contraction, halo recompute not counted) against the 2.5 PFLOP/s
+        # dense peak, i.e. its matrix-pipe utilisation; `mfma_util` is the same quantity from the PMC pass
+        # (SQ_VALU_MFMA_BUSY_CYCLES, halo included).  `hbm_view`: the bytes such a launch has to move in this design (read l
+        # 256 B, GROUP_LAYERS hoisted terms of 256 B, write l 256 B per sample) against the 8 TB/s; SURVEY 8(d)'s
+        # layer-granular model (1536 B per sample and layer) is given beside it.
         nl = GROUP_LAYERS
         bytes_per_launch = (256 + 256 * nl + 256) * B * T
         flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * nl * B * T      # without the hoisted 1x1s (the GEMM's)
         achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        executed_tf = 3 * flops_per_launch / avg_layer_s / 1e12
         kernel_key = 'iaf_group_kernel'
-        clock_hz = 2.05e9
-        pipe_floor_s = (B * T / 16) * nl * BLOCK_LAYER_PIPE_CYCLES / 1024 / clock_hz
+        clk = clock_hz or 2.1e9
+        mfma_floor_s = (B * T / 16) * nl * BLOCK_LAYER_MFMA_CYCLES / 1024 / clk
         roof = {'kernel': 'iaf_group_kernel (wn_iaf_g.hip: {} residual layers per launch on hoisted conditioning, l resident '
                           'in LDS, causal halo recomputed; natural and decimated groups alternate)'.format(nl),
-                'bound': 'hbm', 'achieved': achieved_gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                'frac': achieved_gbps / PEAK_HBM_GBPS,
+                'bound': 'mfma', 'achieved': executed_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': executed_tf / PEAK_F16_MFMA_TFLOPS,
+                'bound_note': 'SIMD issue per CU: matrix pipe + the VALU work beside it (gate, fp16 split / join); not HBM',
                 'layers_per_launch': nl,
+                'hbm_view': {'bytes_per_launch': bytes_per_launch, 'GBps': achieved_gbps, 'frac': achieved_gbps / PEAK_HBM_GBPS},
                 'survey_8d_view': {'bytes_per_launch': LAYER_BYTES_PER_SAMPLE * nl * B * T,
                                    'GBps': LAYER_BYTES_PER_SAMPLE * nl * B * T / avg_layer_s / 1e9,
                                    'frac': LAYER_BYTES_PER_SAMPLE * nl * B * T / avg_layer_s / 1e9 / PEAK_HBM_GBPS,
                                    'note': '1536 B per sample and layer (each layer reads l and enc, writes l): the traffic '
                                            'this launch replaces'},
-                'pipe_view': {'floor_us': pipe_floor_s * 1e6, 'frac_of_floor': pipe_floor_s / avg_layer_s,
-                              'executed_fp16_TFLOPs': 3 * flops_per_launch / avg_layer_s / 1e12,
-                              'note': 'per 16-sample block and layer a SIMD needs 84 MFMAs (1344 cycles) + the gate / split '
-                                      'epilogue (1164 cycles of VALU and transcendentals), serialised; floor at 2.05 GHz on '
-                                      '1024 SIMDs without halo'}}
+                'pipe_view': {'mfma_floor_us': mfma_floor_s * 1e6, 'frac_of_mfma_floor': mfma_floor_s / avg_layer_s,
+                              'clock_GHz': clk / 1e9,
+                              'note': 'per 16-sample block and layer a SIMD needs 84 MFMAs = 1344 cycles of the matrix '
+                                      'pipe; floor = that on 1024 SIMDs at the recorded shader clock, without halo. '
+                                      'VALU work issues beside the MFMAs on gfx950 (profiles/r04_issue_overlap_ubench.txt), '
+                                      'so this -- not MFMA + VALU -- is the floor'}}
     elif hoisted:
         kernel_key = 'iaf_layer_c_kernel'
         flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * B * T
@@ -266,11 +290,14 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches):
                 'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                 'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
-    roof.update({'traffic': pmc_traffic(B, F, eng.precision, hoisted, kernel_key),
+    pm = pmc_replay(B, F, eng.precision, hoisted, kernel_key)
+    roof.update({'traffic': pm['traffic'], 'mfma_util': pm['mfma_util'], 'pmc_file': pm['file'],
                  'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass of this command on these kernel sources, '
                                  'profiles/; null when no such pass is committed)',
                  'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
                  'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
+    if pm['kernel_us_per_call']:
+        roof['kernel_us_per_call'] = pm['kernel_us_per_call']     # rocprofv3 kernel trace of this command on these sources
     return roof
 
 
@@ -375,7 +402,7 @@ def main():
     if rank == 0:
         total_samples = world * B * T * args.steps
         value = total_samples / elapsed
-        roof = roofline_of(eng, B, F, T, layer_ms, layer_launches)
+        roof = roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz_of(clocks_after))
         # the whole call against SURVEY.md 8(d)'s layer-granular traffic model (98 484 B per generated sample; its
         # "60 % of the HBM roofline" is 48.7 M samples/s per GPU) -- beside the dominant kernel's own figures
         gbps = PATH_BYTES_PER_SAMPLE * (total_samples / world) / elapsed / 1e9
@@ -437,10 +464,23 @@ def main():
             n8 = max(3, min(args.steps, 20))
             el8, lms8, ll8, wav8 = measure(eng, mel8, n8, 2, rank, world, local, dev, 2)
             eng.check_range()
-            r8 = roofline_of(eng, 8, F, T, lms8, ll8)
+            r8 = roofline_of(eng, 8, F, T, lms8, ll8, clock_hz_of(clocks_after))
             r8.update({'batch_per_gpu': 8, 'steps': n8, 'ms_per_step': el8 / n8 * 1e3,
                        'samples_per_sec': 8 * T * n8 / el8})
             rec['roofline_b8'] = r8
+        # (3) the same workload in the reference's own arithmetic: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the
+        #     split-fp16 contraction -- driver-timed beside the headline figure
+        if eng.precision != 'f32':
+            eng32 = Engine(hp, kind='student', device=dev, precision='f32').load_weights(weights)
+            n32 = max(3, min(args.steps, 20))
+            el32, lms32, ll32, wav32 = measure(eng32, mel, n32, 2, rank, world, local, dev, 2)
+            assert bool(torch.isfinite(wav32).all())
+            r32 = roofline_of(eng32, B, F, T, lms32, ll32, clock_hz_of(clocks_after))
+            path_tf = PATH_FLOP_PER_SAMPLE * B * T * n32 / el32 / 1e12
+            r32.update({'precision': 'f32', 'steps': n32, 'ms_per_step': el32 / n32 * 1e3, 'samples_per_sec': B * T * n32 / el32,
+                        'path_achieved_tflops': path_tf, 'path_frac_of_f32_mfma_peak': path_tf / PEAK_F32_MFMA_TFLOPS})
+            rec['roofline_f32'] = r32
+            eng32.close()
     if world > 1 and not args.no_extras:
         # The per-GPU shares of BASELINE configs[2] (64 utterances over 8 GPUs = 8 per GPU, this model) and configs[4]
         # (parallel_wavenet_gauss.json as shipped, 128 over 8 = 16 per GPU): timed on every rank, MAX over ranks,

@@ -1,5 +1,5 @@
 """Build a profiles/rNN_pmc_summary_*.json from the rocprofv3 --pmc passes of scripts/pmc_layer.sh.
-    python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json [batch_per_gpu] [bench args]
+    python scripts/pmc_summary.py gpurun_out/pmc_<tag> profiles/r01_pmc_summary_f16x3.json [batch_per_gpu] [bench args] [kernel_stats.csv] [calls]
 Kernels are keyed by their base name; variants that do different work per launch keep their own key
 ("iaf_layer_h_kernel<first>": start conv fused in; "iaf_layer_c_kernel<head>": flow head in the epilogue; "iaf_group_kernel<first>" / "<head>": layer groups that open / close a flow;
 "iaf_pair_c_kernel<...>": per template arguments)."""
@@ -18,6 +18,8 @@ if len(measured_hash) != 64:
     sys.exit('{}/source_hash.txt does not hold a sha256'.format(src))
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 extra = sys.argv[4] if len(sys.argv) > 4 else ''
+stats_csv = sys.argv[5] if len(sys.argv) > 5 else None      # rocprofv3 --kernel-trace --stats of the same command, same run
+stats_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 23  # calls of the generate path in that run (steps + warm-up)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 
@@ -56,7 +58,20 @@ for k, d in agg.items():
     e = {c: round(v / cnt[(k, c)], 1) for c, v in d.items()}
     if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
         e['hbm_bytes_per_launch'] = int((2 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024)
+    if e.get('SQ_VALU_MFMA_BUSY_CYCLES') and e.get('GRBM_GUI_ACTIVE'):
+        # matrix-pipe busy cycles summed over the chip's 1024 SIMDs / (1024 x cycles of the launch); GRBM_GUI_ACTIVE
+        # is summed over the 8 XCDs (scripts/ubench/run_issue_overlap.sh calibrates both on hand-placed MFMA streams)
+        e['mfma_util'] = round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (e['GRBM_GUI_ACTIVE'] / 8.0), 4)
     kernels[k] = e
+kernel_us = {}
+if stats_csv:
+    tot = collections.defaultdict(float)
+    for row in csv.DictReader(open(stats_csv)):
+        k = key_of(row['Name'])
+        if k is None:
+            continue
+        tot[k] += float(row['TotalDurationNs'])
+    kernel_us = {k: round(v / 1e3 / stats_steps, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1]) if v / 1e3 / stats_steps >= 0.5}
 out = {
     '_about': 'rocprofv3 --pmc passes (scripts/pmc_layer.sh: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass, instruction-mix '
               'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ' + extra + '`, one MI355X, '
@@ -70,6 +85,9 @@ out = {
     # while the sources it runs are the same
     'source_hash': measured_hash,
     'kernels': kernels,
+    # microseconds per generate call and kernel (rocprofv3 --kernel-trace --stats of the same command in the same run;
+    # kernels under 0.5 us per call left out): where the call's time goes
+    'kernel_us_per_call': kernel_us,
 }
 json.dump(out, open(dst, 'w'), indent=1)
 for k in sorted(kernels):

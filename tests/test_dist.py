@@ -104,17 +104,21 @@ def test_bench_traffic_figure_follows_the_source_hash(monkeypatch, tmp_path):
     from nsynth_wavenet_amd import build
     dom = bench.DOMINANT_KERNEL
     summary = {'workload': {'batch_per_gpu': 1, 'frames': 384, 'samples': 76800}, 'source_hash': 'a' * 64,
-               'kernels': {dom: {'hbm_bytes_per_launch': 61000000}, dom + '<head>': {'hbm_bytes_per_launch': 99000000}}}
+               'kernels': {dom: {'hbm_bytes_per_launch': 61000000, 'mfma_util': 0.31}, dom + '<head>': {'hbm_bytes_per_launch': 99000000}},
+               'kernel_us_per_call': {dom: 700.0, 'iaf_cond_h_kernel': 390.0}}
     os.makedirs(tmp_path / 'profiles')
     with open(tmp_path / 'profiles' / (bench.PROFILE_ROUND + '_pmc_summary_f16x3.json'), 'w') as f:
         json.dump(summary, f)
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
     monkeypatch.setattr(build, 'source_hash', lambda: 'a' * 64)
-    assert bench.pmc_traffic(1, 384, 'f16x3', True) == 61000000
-    assert bench.pmc_traffic(8, 384, 'f16x3', True) is None           # another workload
-    assert bench.pmc_traffic(1, 384, 'f16x3-fused', True) is None     # no summary of its own: nothing borrowed
+    got = bench.pmc_replay(1, 384, 'f16x3', True)
+    assert got['traffic'] == 61000000 and got['mfma_util'] == 0.31 and got['kernel_us_per_call']['iaf_cond_h_kernel'] == 390.0
+    assert bench.pmc_replay(8, 384, 'f16x3', True)['traffic'] is None           # another workload
+    assert bench.pmc_replay(1, 384, 'f16x3-fused', True)['traffic'] is None     # no summary of its own: nothing borrowed
     monkeypatch.setattr(build, 'source_hash', lambda: 'not-the-measured-sources')
-    assert bench.pmc_traffic(1, 384, 'f16x3', True) is None
+    stale = bench.pmc_replay(1, 384, 'f16x3', True)
+    assert stale['traffic'] is None and stale['mfma_util'] is None and stale['kernel_us_per_call'] is None
+    assert bench.clock_hz_of({'sclk': '(2105Mhz)', 'mclk': '(2000Mhz)'}) == 2105e6 and bench.clock_hz_of(None) is None
     # the committed summary of this round, when present, must describe the kernel bench.py calls dominant
     real = os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_pmc_summary_f16x3.json')
     if os.path.exists(real):
