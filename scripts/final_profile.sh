@@ -1,6 +1,6 @@
 # final measurement pass of a round (run through gpurun): tests, bench lines, kernel stats, PMC passes
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2 | tee gpurun_out/gputest_final.txt
 timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_f16x3_driver_protocol.json
 WN_NO_GROUPS=1 timeout 300 python bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 > gpurun_out/bench_f16x3_per_layer.json
@@ -21,3 +21,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
 cd $R; for f in gpurun_out/bench_*.json; do python -c "
 import json; d=json.load(open('$f')); r=d['roofline']; print('$f', round(d['value']/1e6,3),'Ms/s', round(d['ms_per_step'],3),'ms', r['bound'], round(r['achieved'],1), round(r['frac'],3), r.get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done
+# batch sweep of the two launch structures (policy of wn_iaf_use_groups): ms per call
+for b in 1 2 3 4 8; do
+  WN_GROUPS=1 python scripts/dev_abl_bench.py --tag groups --batch $b --steps 40 2>/dev/null | tail -1
+  WN_NO_GROUPS=1 python scripts/dev_abl_bench.py --tag per-layer --batch $b --steps 40 2>/dev/null | tail -1
+done | tee gpurun_out/batch_sweep.txt
