@@ -129,7 +129,8 @@ int wn_abi_version(void);
  * Students of the shipped shape (width 64, deconv_width 256, num_stages >= 7) run on the MFMA kernels; any other even
  * width <= 416 (one tile of the generic layer kernel must fit the 160 KB of LDS) / deconv_width % 64 == 0 /
  * num_stages >= 3 on generic fp32 kernels (same results, much slower).
- * Teachers need 3 * width + deconv_width <= 2048. */
+ * Teachers: 3 * width + deconv_width <= 2048 runs on the tuned step kernels (every shipped wavenet_*.json), up to 4096 on
+ * a wide instantiation of the same kernels (one utterance at a time: a correctness path); beyond that wn_create refuses. */
 int wn_create(const wn_config* cfg_host, wn_handle** out);
 
 /* Provide one variable under its TensorFlow name WITHOUT the
@@ -297,7 +298,7 @@ int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
 /* 1 when wn_iaf_generate(B, F) runs the residual layers in layer groups (up to five layers per launch with the residual
  * stream in LDS: one natural and one decimated group per ten-layer dilation cycle) -- the default of the hoisted form for
- * small calls (up to three utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
+ * small calls (up to four utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
  * (or layer pair) is a launch of its own.  Environment WN_GROUPS=1 / WN_NO_GROUPS=1 force either. */
 int wn_iaf_layer_groups(const wn_handle* h, int B, int F);
 

@@ -49,6 +49,11 @@ __host__ __device__ inline int arp_pairs(int B, int W, int S, int G, int OW) {
     return 2 * B * G + 2 * B * W + 2 * B * S + B * ((OW + 1) & ~1) + ((B + 1) & ~1);
 }
 
+// rows of the GEMV step past the default register tiles (AR_NCA / AR_NCH chunks of 256 floats): the wide instantiation
+static bool ar_wide(const wn_config& c) {
+    return 3 * c.width + c.deconv_width > 2048 || c.gate_width / 2 > 1024 || c.width > 1024;
+}
+
 int ar_padded_batch(int B, bool has_b_pack = true) {
     const char* mode = getenv("WN_AR_MODE");                  // "gemv" | "mfma" override (tests, A/B)
     if (mode && !strcmp(mode, "gemv")) return 0;
@@ -194,9 +199,13 @@ __global__ __launch_bounds__(256) void ar_rows_kernel(
 // the kernel even starts -- and so are the inputs that live in global memory; inputs produced by
 // the prologue come from LDS afterwards.  The kernels are one or two memory round trips long, so
 // the number of SEQUENTIAL round trips is what matters.
-constexpr int AR_NCA = 8;    // chunks of the dilated + cond row (3W + Cd <= 2048, checked in wn_pack_ar)
+constexpr int AR_NCA = 8;    // chunks of the dilated + cond row: 3W + Cd <= 2048 (every shipped teacher)
 constexpr int AR_NCH = 4;    // chunks of an H-long row (gate_width / 2 <= 1024)
 constexpr int AR_GEMV_MAXB = 3;   // the GEMV step serves batches below 4 (ar_padded_batch)
+// Wide teachers (masked.py takes any width): the same kernels with rows of up to 4096 / 2048 floats in registers and one
+// utterance at a time (three utterances' inputs beside a 4096-float row would not fit the register file); such shapes have
+// no batched pack (AR_MAXSLAB), so this instantiation serves every batch size -- a correctness path, like wn_iaf_x.hip
+constexpr int AR_NCA_W = 16, AR_NCH_W = 8, AR_GEMV_MAXB_W = 1;
 
 // sigmoid(a) * tanh(b) with the hardware exp / rcp (abs error ~1e-7, as in the IAF kernels)
 __device__ inline float ar_gate(float a, float b) {
@@ -236,14 +245,16 @@ __device__ inline float row_fma(const RowW<NC>& r, int K, int lane, XF xload) {
 }
 
 // inputs of the dilated + cond row that live in global memory: [ring(t-2d) | ring(t-d) | (lin: LDS) | enc]
+template <int NCA = AR_NCA>
 struct GateX {
-    f4 x[AR_NCA];
+    f4 x[NCA];
 };
-__device__ inline GateX gate_x_load(const float* ring2, const float* ring1, const float* enc_t, int W, int Cd, int lane) {
-    GateX g;
+template <int NCA = AR_NCA>
+__device__ inline GateX<NCA> gate_x_load(const float* ring2, const float* ring1, const float* enc_t, int W, int Cd, int lane) {
+    GateX<NCA> g;
     const int K = 3 * W + Cd;
 #pragma unroll
-    for (int i = 0; i < AR_NCA; ++i) {
+    for (int i = 0; i < NCA; ++i) {
         const int k = i * 256 + lane * 4;
         const float* p = k < W ? ring2 + k : k < 2 * W ? ring1 + (k - W) : k < 3 * W ? nullptr : enc_t + (k - 3 * W);
         g.x[i] = (k < K && p) ? *reinterpret_cast<const f4*>(p) : (f4){0.f, 0.f, 0.f, 0.f};
@@ -254,6 +265,7 @@ __device__ inline GateX gate_x_load(const float* ring2, const float* ring1, cons
 // first kernel of a step: lin_0 = conv_start (every workgroup recomputes it: 3 MACs per channel),
 // s = skip_start(lin_0), d_0 = dilated_conv_1 + mel_cond_1 pre-activations.  Rows: [0,S) s, [S,S+G) d.
 // The batch is walked in chunks of AR_GEMV_MAXB (one chunk for the batches this step is chosen for).
+template <int NCA, int NCH, int MB>
 __global__ __launch_bounds__(256) void ar_first_m_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, const float* __restrict__ wav_in,
     const float* __restrict__ forced, int Tn, const float* __restrict__ wb, const float* __restrict__ Wss,
@@ -269,25 +281,25 @@ __global__ __launch_bounds__(256) void ar_first_m_kernel(
     const float* ring = state + L.rings + (size_t)D.B * ring_off;
     const size_t slot2 = (size_t)((t + 1) % (2 * dil + 1)) * D.B;          // lin_0[t-2d]
     const size_t slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.B;    // lin_0[t-d]
-    RowW<AR_NCA> wd;
-    RowW<AR_NCH> ws;
+    RowW<NCA> wd;
+    RowW<NCH> ws;
     float bias = 0.f;
     if (is_d) {
-        wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
+        wd = row_load<NCA>(Wd + (size_t)r * K, K, lane);
         bias = bd[r];
     } else if (is_s) {
-        ws = row_load<AR_NCH>(Wss + (size_t)o * D.W, D.W, lane);
+        ws = row_load<NCH>(Wss + (size_t)o * D.W, D.W, lane);
         bias = bss[o];
     }
     float* ur = state + L.uring;
-    for (int b0 = 0; b0 < D.B; b0 += AR_GEMV_MAXB) {
-        const int nb = min(AR_GEMV_MAXB, D.B - b0);
-        GateX gx[AR_GEMV_MAXB];
+    for (int b0 = 0; b0 < D.B; b0 += MB) {
+        const int nb = min(MB, D.B - b0);
+        GateX<NCA> gx[MB];
         if (is_d) {
 #pragma unroll
-            for (int e = 0; e < AR_GEMV_MAXB; ++e)
+            for (int e = 0; e < MB; ++e)
                 if (e < nb)
-                    gx[e] = gate_x_load(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
+                    gx[e] = gate_x_load<NCA>(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
                                         enc + ((size_t)(b0 + e) * Tn + ti) * D.Cd, D.W, D.Cd, lane);
         }
         for (int i = threadIdx.x; i < nb * D.W; i += 256) {
@@ -308,16 +320,16 @@ __global__ __launch_bounds__(256) void ar_first_m_kernel(
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+        for (int e = 0; e < MB; ++e) {
             if (e >= nb || !(is_s || is_d)) break;
             const int b = b0 + e;
             const float* lin = sh + (size_t)e * D.W;
             if (is_s) {
-                const float v = wave_sum(row_fma<AR_NCH>(ws, D.W, lane, [&](int, int k) {
+                const float v = wave_sum(row_fma<NCH>(ws, D.W, lane, [&](int, int k) {
                     return *reinterpret_cast<const f4*>(lin + k); })) + bias;
                 if (lane == 0) state[L.s + (size_t)b * D.S + o] = v;
             } else {
-                const float v = wave_sum(row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                const float v = wave_sum(row_fma<NCA>(wd, K, lane, [&](int i, int k) {
                     return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[e].x[i]; })) + bias;
                 if (lane == 0) state[L.dbuf + (size_t)b * D.G + r] = v;                       // d_0, buffer 0
             }
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256) void ar_first_m_kernel(
 
 // layer kernel j = 1..N (N = LAST): rows [0,W) lin_j (+ ring push), [W,W+S) s += skip_{j-1},
 // [W+S, W+S+G) d_j.  LAST: only the skip rows (lin_N and d_N do not exist).
-template <bool LAST>
+template <bool LAST, int NCA, int NCH, int MB>
 __global__ __launch_bounds__(256) void ar_layer_m_kernel(
     float* __restrict__ state, ArStateLayout L, ArDims D, int cur, const float* __restrict__ Wrs,
     const float* __restrict__ brs, const float* __restrict__ Wd, const float* __restrict__ Wcomp,
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
     extern __shared__ __attribute__((aligned(16))) float sh[];          // m [chunk][H] | lin_{j-1} [chunk][W]
     const int H = D.G / 2;
     float* shm = sh;
-    float* shl = sh + (size_t)AR_GEMV_MAXB * H;
+    float* shl = sh + (size_t)MB * H;
     const long long t = ar_step_of(state);
     const long long ti = per_step ? 0 : t;
     const int lane = threadIdx.x & 63;
@@ -348,30 +360,30 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
     const size_t slot2 = (size_t)((t + 1) % (2 * dil + 1)) * D.B;
     const size_t slot1 = (size_t)((t + dil + 1) % (2 * dil + 1)) * D.B;
     // all global loads of this wave's row are in flight before the gate prologue
-    RowW<AR_NCA> wd;
-    RowW<AR_NCH> wh;
+    RowW<NCA> wd;
+    RowW<NCH> wh;
     float bias = 0.f;
     if (is_d) {
-        wd = row_load<AR_NCA>(Wd + (size_t)r * K, K, lane);
-        wh = row_load<AR_NCH>(Wcomp + (size_t)r * H, H, lane);
+        wd = row_load<NCA>(Wd + (size_t)r * K, K, lane);
+        wh = row_load<NCH>(Wcomp + (size_t)r * H, H, lane);
         bias = bm[r];
     } else if (is_rs) {
-        wh = row_load<AR_NCH>(Wrs + (size_t)row * H, H, lane);
+        wh = row_load<NCH>(Wrs + (size_t)row * H, H, lane);
         bias = brs[row];
     }
     const float* dprev = state + L.dbuf + (size_t)cur * D.B * D.G;
     const float* lprev = state + (cur ? L.l2 : L.l);
     const int nxt = cur ^ 1;
-    for (int b0 = 0; b0 < D.B; b0 += AR_GEMV_MAXB) {
-        const int nb = min(AR_GEMV_MAXB, D.B - b0);
-        GateX gx[AR_GEMV_MAXB];
-        float sold[AR_GEMV_MAXB];      // skip rows accumulate into s: fetched with the other loads
+    for (int b0 = 0; b0 < D.B; b0 += MB) {
+        const int nb = min(MB, D.B - b0);
+        GateX<NCA> gx[MB];
+        float sold[MB];      // skip rows accumulate into s: fetched with the other loads
 #pragma unroll
-        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+        for (int e = 0; e < MB; ++e) {
             sold[e] = 0.f;
             if (e < nb) {
                 if (is_d)
-                    gx[e] = gate_x_load(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
+                    gx[e] = gate_x_load<NCA>(ring + (slot2 + b0 + e) * D.W, ring + (slot1 + b0 + e) * D.W,
                                         enc + ((size_t)(b0 + e) * Tn + ti) * D.Cd, D.W, D.Cd, lane);
                 if (is_rs && row >= D.W) sold[e] = state[L.s + (size_t)(b0 + e) * D.S + (row - D.W)];
             }
@@ -386,13 +398,13 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
             for (int i = threadIdx.x; i < nb * D.W; i += 256) shl[i] = lprev[(size_t)b0 * D.W + i];
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < AR_GEMV_MAXB; ++e) {
+        for (int e = 0; e < MB; ++e) {
             if (e >= nb || !(is_rs || is_d)) break;
             const int b = b0 + e;
             const float* m = shm + (size_t)e * H;
             const float* lin = shl + (size_t)e * D.W;
             if (is_rs) {
-                const float v = wave_sum(row_fma<AR_NCH>(wh, H, lane, [&](int, int k) {
+                const float v = wave_sum(row_fma<NCH>(wh, H, lane, [&](int, int k) {
                     return *reinterpret_cast<const f4*>(m + k); })) + bias;
                 if (lane == 0) {
                     if (row < D.W) {
@@ -405,9 +417,9 @@ __global__ __launch_bounds__(256) void ar_layer_m_kernel(
                     }
                 }
             } else {
-                float acc = row_fma<AR_NCA>(wd, K, lane, [&](int i, int k) {
+                float acc = row_fma<NCA>(wd, K, lane, [&](int i, int k) {
                     return (k >= 2 * D.W && k < 3 * D.W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * D.W)) : gx[e].x[i]; });
-                acc += row_fma<AR_NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
+                acc += row_fma<NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
                 const float v = wave_sum(acc) + bias;
                 if (lane == 0) state[L.dbuf + (size_t)nxt * D.B * D.G + (size_t)b * D.G + r] = v;
             }
@@ -951,8 +963,8 @@ __device__ inline void arp_put(arp_rsrc_t rx, int pair, float v, unsigned tag, i
     __builtin_amdgcn_raw_buffer_store_b64((wn_u2){__float_as_uint(v), tag}, rx, lane == 0 ? pair * 8 : ARP_OOB, 0, ARP_SC1);
 }
 // [ring(t-2d) | ring(t-d) | (lin: LDS) | enc]: the ring words were written by other workgroups -> sc1 loads
-__device__ inline GateX arp_gate_x(arp_rsrc_t rst, size_t ring2, size_t ring1, const float* enc_t, int W, int Cd, int lane) {
-    GateX g;
+__device__ inline GateX<> arp_gate_x(arp_rsrc_t rst, size_t ring2, size_t ring1, const float* enc_t, int W, int Cd, int lane) {
+    GateX<> g;
     const int K = 3 * W + Cd;
 #pragma unroll
     for (int i = 0; i < AR_NCA; ++i) {
@@ -1067,7 +1079,7 @@ __global__ __launch_bounds__(ARP_THREADS, 1) void ar_persist_kernel(const ArpArg
             const size_t slot2 = (size_t)((t + 1) % (2 * l0.dil + 1)) * B, slot1 = (size_t)((t + l0.dil + 1) % (2 * l0.dil + 1)) * B;
             RowW<AR_NCA> wd;
             RowW<AR_NCH> ws;
-            GateX gx[NB];
+            GateX<> gx[NB];
             float bias = 0.f;
             auto fetch = [&](int row) {
                 if (row >= W && row < W + S) {
@@ -1170,7 +1182,7 @@ __global__ __launch_bounds__(ARP_THREADS, 1) void ar_persist_kernel(const ArpArg
             const size_t slot2 = (size_t)((t + 1) % (2 * lp.dil + 1)) * B, slot1 = (size_t)((t + lp.dil + 1) % (2 * lp.dil + 1)) * B;
             RowW<AR_NCA> wd;
             RowW<AR_NCH> wh;
-            GateX gx[NB];
+            GateX<> gx[NB];
             float bias = 0.f;
             auto fetch = [&](int row) {
                 if (row < W + S) {
@@ -1357,22 +1369,27 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
     const ArPack& P = h->ar;
     const float* blob = h->d_blob;
     {
-        // merged step: one launch per layer (see ar_layer_m_kernel)
+        // merged step: one launch per layer (see ar_layer_m_kernel); the wide instantiation for rows past the default tiles
         const size_t n = P.layers.size();
         const ArLayerPack& l0 = P.layers[0];
-        hipLaunchKernelGGL(ar_first_m_kernel, dim3((D.S + D.G + 3) / 4), dim3(256), (size_t)AR_GEMV_MAXB * D.W * sizeof(float), st,
+        const bool wide = ar_wide(h->cfg);
+        const int mb = wide ? AR_GEMV_MAXB_W : AR_GEMV_MAXB;
+        auto first = wide ? ar_first_m_kernel<AR_NCA_W, AR_NCH_W, AR_GEMV_MAXB_W> : ar_first_m_kernel<AR_NCA, AR_NCH, AR_GEMV_MAXB>;
+        auto layer = wide ? ar_layer_m_kernel<false, AR_NCA_W, AR_NCH_W, AR_GEMV_MAXB_W> : ar_layer_m_kernel<false, AR_NCA, AR_NCH, AR_GEMV_MAXB>;
+        auto lastk = wide ? ar_layer_m_kernel<true, AR_NCA_W, AR_NCH_W, AR_GEMV_MAXB_W> : ar_layer_m_kernel<true, AR_NCA, AR_NCH, AR_GEMV_MAXB>;
+        hipLaunchKernelGGL(first, dim3((D.S + D.G + 3) / 4), dim3(256), (size_t)mb * D.W * sizeof(float), st,
                            state, L, D, wav_in, forced, Tn, blob + P.start_off, blob + P.wss_off, blob + P.bss_off,
                            blob + l0.wd_off, blob + l0.bd_off, enc, per_step, l0.ring_off, l0.dilation);
-        const size_t shb = (size_t)AR_GEMV_MAXB * (D.G / 2 + D.W) * sizeof(float);
+        const size_t shb = (size_t)mb * (D.G / 2 + D.W) * sizeof(float);
         for (size_t j = 1; j < n; ++j) {
             const ArLayerPack& lp = P.layers[j];
             const ArLayerPack& pv = P.layers[j - 1];
-            hipLaunchKernelGGL(ar_layer_m_kernel<false>, dim3((D.W + D.S + D.G + 3) / 4), dim3(256), shb, st, state, L, D,
+            hipLaunchKernelGGL(layer, dim3((D.W + D.S + D.G + 3) / 4), dim3(256), shb, st, state, L, D,
                                (int)((j - 1) & 1), blob + pv.wrs_off, blob + pv.brs_off, blob + lp.wd_off,
                                blob + lp.wcomp_off, blob + lp.bm_off, enc, Tn, per_step, lp.ring_off, lp.dilation);
         }
         const ArLayerPack& pl = P.layers[n - 1];
-        hipLaunchKernelGGL(ar_layer_m_kernel<true>, dim3((D.S + 3) / 4), dim3(256), shb, st, state, L, D,
+        hipLaunchKernelGGL(lastk, dim3((D.S + 3) / 4), dim3(256), shb, st, state, L, D,
                            (int)((n - 1) & 1), blob + pl.wrs_off, blob + pl.brs_off, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, enc, Tn, per_step, (size_t)0, 1);
         hipLaunchKernelGGL(ar_rows_kernel<2>, dim3((D.S + 3) / 4), dim3(256), 0, st, state, L, D, blob + P.wo1_off,
@@ -1391,7 +1408,7 @@ bool ar_persist_ok(const wn_handle* h, int B) {
     // the kernel is opt-in (WN_AR_PERSIST=1), kept parity-tested
     const char* pe = getenv("WN_AR_PERSIST");
     const bool off = !(pe && atoi(pe) != 0);
-    if (off || B > AR_GEMV_MAXB || ar_padded_batch(B, h->ar.wss_b_off != 0) != 0) return false;
+    if (off || B > AR_GEMV_MAXB || ar_padded_batch(B, h->ar.wss_b_off != 0) != 0 || ar_wide(h->cfg)) return false;
     const wn_config& c = h->cfg;
     const int W = c.width, S = c.skip_width, G = c.gate_width, Cd = c.deconv_width, OW = c.out_width;
     if ((W | S | Cd | (G / 2)) & 3) return false;                       // 16-byte operand chunks, even pair regions

@@ -135,12 +135,13 @@ static int validate(const wn_config& c) {
             return wn_fail(nullptr, WN_EINVAL, "config: out_width %d != %d implied by loss_type", c.out_width, ow);
         if (c.num_layers < 1 || c.num_layers > 256)
             return wn_fail(nullptr, WN_EINVAL, "config: bad num_layers");
-        // fixed register tiles of the AR step kernels (wn_ar.hip: a wave holds one weight row in AR_NCA = 8 /
-        // AR_NCH = 4 chunks of 256 floats; the MoL selection scores live in a 64-entry LDS array)
-        if (3 * c.width + c.deconv_width > 2048 || c.width > 1024 || c.skip_width > 1024 || c.gate_width / 2 > 1024)
+        // register tiles of the AR step kernels (wn_ar.hip): a wave holds one weight row in chunks of 256 floats -- 8 / 4
+        // chunks for the shipped shapes (3 * width + deconv_width <= 2048, gate_width / 2 <= 1024), 16 / 8 in the wide
+        // instantiation; the MoL selection scores live in a 64-entry LDS array
+        if (3 * c.width + c.deconv_width > 4096 || c.skip_width > 2048 || c.gate_width / 2 > 2048)
             return wn_fail(nullptr, WN_EINVAL,
                            "config: the autoregressive step kernels hold a weight row in registers and need "
-                           "3*width + deconv_width <= 2048, width <= 1024, skip_width <= 1024, gate_width/2 <= 1024; "
+                           "3*width + deconv_width <= 4096, skip_width <= 2048, gate_width/2 <= 2048; "
                            "got width %d skip %d gate %d deconv %d", c.width, c.skip_width, c.gate_width, c.deconv_width);
         if (c.loss_type == WN_LOSS_MOL && (c.mol_mix < 1 || c.mol_mix > 64))
             return wn_fail(nullptr, WN_EINVAL, "config: mol_mix must be in 1..64, got %d", c.mol_mix);

@@ -937,16 +937,16 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 
 // The layer-group kernel (wn_iaf_g.hip) runs the hoisted form whenever every flow has a group plan and the decimated
 // view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the whole call.
-// Where it pays: the group kernel is compute-bound per CU (its halo costs 28 % more matrix and VALU work, and the two
-// do not overlap on a gfx950 SIMD, scripts/ubench/mfma_valu_overlap.hip) and wins by launching 12 times instead of
-// 52 -- end of round 3, configs[1] utterances on one box: + 13 % at one, + 7 % at two, + 2 % at three, - 1.5 % at four,
-// - 1 % at eight, where the per-layer launches keep the GPU full.
-// Default: while a natural group has at most three segments per CU.  WN_GROUPS=1 forces it on at any batch size,
+// Where it pays: the group launch is bound by the SIMD issue of a CU (its halo costs 17 % more matrix and VALU work than the
+// per-layer kernels, which in turn pay a launch per layer or layer pair).  End of round 4 (profiles/r04_batch_sweep.txt,
+// configs[1] utterances on one box, ms per call groups | per-layer launches): 1.254 | 1.494 at one, 2.465 | 2.695 at two,
+// 3.651 | 3.811 at three, 4.808 | 4.893 at four, 9.448 | 9.482 at eight (a tie).
+// Default: while a natural group has at most four segments per CU.  WN_GROUPS=1 forces it on at any batch size,
 // WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
     if (h->groups_env) return h->groups_env > 0;                // WN_NO_GROUPS / WN_GROUPS, resolved once in wn_create
-    return (int64_t)B * ((T / 16 + 19) / 20) <= 3 * (int64_t)h->num_cu;
+    return (int64_t)B * ((T / 16 + 19) / 20) <= 4 * (int64_t)h->num_cu;
 }
 
 extern "C" int wn_iaf_layer_groups(const wn_handle* h, int B, int F) {

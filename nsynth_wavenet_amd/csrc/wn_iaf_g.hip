@@ -183,8 +183,9 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         // LDS blocks of this wave: wave + 12 e.  The blocks a late layer skips (its `first`: the halo, blocks 0 .. 3 for
         // the fifth layer) then belong to four different waves on four different SIMDs, so every SIMD loses one of its six
         // blocks there; with adjacent blocks per wave two SIMDs would skip two and the barrier would wait for the others.
-        // (Giving those four blocks to waves 8 .. 11 -- the youngest wave of every SIMD, whose epilogue nothing hides --
-        // measured no gain: 58.1 against 57.7 us per launch.)
+        // (Round 4, measured and not kept: those four blocks given to waves 8 .. 11, the youngest wave of every SIMD, whose
+        // epilogue nothing hides: 58.1 against 57.7 us per launch; uneven shares -- three blocks for the oldest wave of a
+        // SIMD, two, one for the youngest: 92 us, the three-block waves spill at 168 registers.)
         auto blk_of = [&](int e) { return wave + GK_WAVES * e; };
         auto active = [&](int i) { return (unsigned)(blk0 + i) < (unsigned)A.nbu; };
         // time of column n of LDS block i

@@ -298,11 +298,46 @@ def test_persistent_step_kernel_matches_the_launched_step(tag, monkeypatch):
 
 
 def test_teacher_configs_outside_the_kernel_limits_are_refused():
-    """The AR step kernels hold one weight row in a fixed register tile: 3*width + deconv_width <= 2048,
-    gate_width/2 <= 1024, 1 <= mol_mix <= 64 -- anything else must fail at wn_create, not truncate a dot product."""
+    """The AR step kernels hold one weight row in a register tile: 3*width + deconv_width <= 4096 (2048 on the tuned
+    instantiation, the rest on the wide one), gate_width/2 <= 2048, 1 <= mol_mix <= 64 -- anything else must fail at
+    wn_create, not truncate a dot product."""
     from nsynth_wavenet_amd.engine import Engine
     base = load_json('wavenet_mol.json')
-    for bad in (dict(width=768, skip_width=256), dict(mol_mix=65), dict(mol_mix=0)):
+    for bad in (dict(width=1408, skip_width=256), dict(mol_mix=65), dict(mol_mix=0)):
         with pytest.raises(ValueError):
             Engine(dict(base, **bad))
     Engine(dict(base, mol_mix=64)).close()
+
+
+@pytest.mark.parametrize('patch', [
+    dict(width=768, skip_width=256),                                    # 3 * 768 + 256 = 2560: past the tuned tile, gate = width
+    dict(width=640, skip_width=512, double_gate_width=True),            # gate 1280: H = 640, d row 2176
+    dict(width=1024, skip_width=256, deconv_width=512,                  # 3584-float rows, the widest class
+         deconv_config=[[40, 10], [80, 20]]),
+])
+def test_wide_teachers_run_on_the_wide_instantiation(patch):
+    """masked.conv1d / Fastgen.sample take any width (wavenet.py:326-345,379-514; masked.py:328-405).  Shapes whose weight
+    rows do not fit the tuned register tiles (3 * width + deconv_width > 2048) used to be refused; they now run on a wide
+    instantiation of the same step kernels (one utterance at a time) -- same C ABI, same oracle: K1 against the float64
+    full-sequence teacher, batch rows independent, free run reproducible, both step forms where a batched pack exists."""
+    import torch
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    cfgd = dict(load_json('wavenet_mol.json'), num_layers=6, num_stages=3, **patch)
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'teacher', seed=4321, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    Cd = cfgd['deconv_width']
+    rs = np.random.RandomState(1)
+    for B in (1, 3, 5):
+        Tn = 32
+        enc = (rs.standard_normal([B, Tn, Cd]) * 0.3).astype(np.float32)
+        forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+        out = eng.ar_generate(enc, None, seed=1, forced_wav=forced, want_out=True)
+        ref = O.teacher_feed_forward(forced.astype(np.float64), enc.astype(np.float64), w, hp, np.float64)
+        assert np.abs(_np(out['out_params']) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), (patch, B)
+        a = eng.ar_generate(enc, None, seed=5)
+        b = eng.ar_generate(enc, None, seed=5)
+        c = eng.ar_generate(enc[:1], None, seed=5)
+        assert torch.equal(a['idx'], b['idx']) and torch.equal(a['idx'][:1], c['idx'])
+    eng.close()
