@@ -15,6 +15,13 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, os.environ.get('WN_LIB_NAME', 'libwnhip.so'))     # WN_LIB_NAME: variant builds for A/B runs
+# Code-generation flags of every kernel source.  -fno-slp-vectorize: the SLP vectorizer pairs scalar fp32 operations into
+# v_pk_*_f32 and folds "both lanes take the same register" into operand selects; the form that takes the HIGH register of
+# src1 for the low lane is not reliable on gfx950 next to matrix instructions (tests/test_gpu_hazards.py,
+# scripts/ubench/pk_opsel.hip, profiles/r04_pk_opsel_hazard.txt).  Without the pass the compiler emits no packed-fp32
+# instruction with selects at all (scripts/audit_store_hazard.py checks it), and the kernels are no slower (measured
+# 58.4-59.3 against 60.8-61.1 us per group launch on one box).
+CODEGEN_FLAGS = ['-O3', '-std=c++17', '-fno-slp-vectorize']
 SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_x.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
 HEADERS = ['wn_internal.h', 'wn_codec.h', 'wn_pack_h.h', 'wn_mfma_h.h', 'wn_iaf_c.h', os.path.join(ROOT, 'include', 'wnhip.h')]
 
@@ -44,6 +51,7 @@ def source_hash():
         hh.update(os.path.basename(d).encode() + b'\0')
         with open(d, 'rb') as f:
             hh.update(f.read())
+    hh.update(' '.join(CODEGEN_FLAGS).encode())
     hh.update(os.environ.get('WN_EXTRA_FLAGS', '').encode())
     return hh.hexdigest()
 
@@ -64,7 +72,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     hipcc = find_hipcc()
-    common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
+    common = ['--offload-arch=gfx950'] + CODEGEN_FLAGS + ['-fPIC', '-Wall',
               '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + \
         os.environ.get('WN_EXTRA_FLAGS', '').split()
     procs = []

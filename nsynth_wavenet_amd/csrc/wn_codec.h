@@ -67,9 +67,13 @@ typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
 // gfx950 needs between a VALU write and an MFMA that reads the register (scripts/ubench/valu_to_mfma.hip) are inserted
 // by its hazard recognizer for every consumer, present and future -- the use-site fences the asm form needed are gone.
 __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const wn_h2 h = {(_Float16)x0, (_Float16)x1};
-    const wn_h2 l = {(_Float16)(x0 - (float)h.x), (_Float16)(x1 - (float)h.y)};
-    hi = __builtin_bit_cast(unsigned, h);
+    // The hi word is PACKED from the two scalar conversions the lo halves are computed against.  (Written as a vector
+    // {(_Float16)x0, (_Float16)x1}, the compiler -- without the SLP vectorizer, build.py -- converts twice: a packed
+    // v_cvt_pk_f16_f32 for the word and scalar v_cvt_f16_f32 for the differences, and the two do not agree on fp16
+    // denormals: hi + lo was then off by up to 6e-5 for small values, 100 times the codec's error.)
+    const _Float16 hx = (_Float16)x0, hy = (_Float16)x1;
+    const wn_h2 l = {(_Float16)(x0 - (float)hx), (_Float16)(x1 - (float)hy)};
+    hi = __builtin_amdgcn_perm((unsigned)__builtin_bit_cast(unsigned short, hy), (unsigned)__builtin_bit_cast(unsigned short, hx), 0x05040100u);   // one v_perm_b32
     lo = __builtin_bit_cast(unsigned, l);
 }
 
@@ -80,7 +84,7 @@ __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned&
 // caller re-runs on the fp32-MFMA form (the Python Engine does that by itself).  NaNs do not raise the maximum: one
 // can only come out of an earlier inf, which was flagged where it was produced.
 constexpr float WN_HALF_MAX = 65504.f;
-__device__ inline void wn_range_track(float& amax, float x0, float x1) { amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1))); }
+__device__ inline void wn_range_track(float& amax, float x0, float x1) { amax = __builtin_fmaxf(__builtin_fmaxf(amax, fabsf(x0)), fabsf(x1)); }   // one v_max3_f32
 __device__ inline void wn_range_flag(float amax, unsigned* status) {
     if (status && !(amax < WN_HALF_MAX)) atomicOr(status, 1u);
 }

@@ -130,9 +130,9 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
     float amax = 0.f;
 #ifdef GK_STAMPS
-    // workgroups 0, 37, 74, ... (8 of them), waves 0 and 11
-    const int stamp_slot = (blockIdx.x % 31 == 0 && blockIdx.x / 31 < 8 && (wave == 0 || wave == GK_WAVES - 1) && lane == 0)
-                               ? (int)(blockIdx.x / 31) * 2 + (wave ? 1 : 0) : -1;
+    // workgroups 0, 31, 62, 93, waves 0, 4, 8 (one SIMD's three) and 11
+    const int stamp_w = wave == 0 ? 0 : wave == 4 ? 1 : wave == 8 ? 2 : wave == GK_WAVES - 1 ? 3 : -1;
+    const int stamp_slot = (blockIdx.x % 31 == 0 && blockIdx.x / 31 < 4 && stamp_w >= 0 && lane == 0) ? (int)(blockIdx.x / 31) * 4 + stamp_w : -1;
     unsigned long long* stamp_base = gk_stamps + (stamp_slot < 0 ? 0 : stamp_slot) * 32;
     if (stamp_slot >= 0) { stamp_base[30] = __builtin_amdgcn_s_memrealtime(); stamp_base[29] = 0; }
     GK_STAMP(0);

@@ -23,15 +23,15 @@ __device__ inline f4 mfma3(wn_u4 ah, wn_u4 al, wn_u4 bh, wn_u4 bl, f4 c) {
 // layer packs store the gate biases multiplied by those factors (wn_pack_iaf_h) and the kernels fold them into the
 // de-scaling constant, so an argument is one FMA on the accumulator.  With ea = 2^as and t = 2^-|bt|:
 //   sigmoid(a) = 1 / (1 + ea),   tanh(b) = sign(b) (1 - t) / (1 + t)      ->  ONE reciprocal for the pair,
-// three transcendentals per gate value instead of four and 9 plain VALU operations instead of 12 (the epilogue is half
+// three transcendentals per gate value instead of four and 8 plain VALU operations instead of 12 (the epilogue is half
 // of a layer kernel's time on gfx950, where VALU work does not hide behind the MFMAs).  t <= 1 never overflows; ea = inf
 // (a << 0) gives 1 / inf = 0, the correct limit; |error| ~ 1e-7 like the two-reciprocal form.
 constexpr float WN_LOG2E = 1.4426950408889634f;
 __device__ inline float gate_scaled(float as, float bt) {
     const float ea = __builtin_amdgcn_exp2f(as);
     const float t = __builtin_amdgcn_exp2f(-fabsf(bt));
-    const float r = __builtin_amdgcn_rcpf((1.f + t) * (1.f + ea));
-    return __builtin_copysignf((1.f - t) * r, bt);
+    const float r = __builtin_amdgcn_rcpf((1.f + t) * (1.f + ea));     // (NOT fma(t, 1 + ea, 1 + ea): 0 * inf for a << 0, |b| >> 0)
+    return __builtin_copysignf(fmaf(-t, r, r), bt);                    // (1 - t) r: r <= 1, t <= 1
 }
 __device__ inline float sigmoidf_(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
 __device__ inline float tanhf_(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * a) + 1.f); }

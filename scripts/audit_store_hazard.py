@@ -17,6 +17,16 @@ cannot see into an asm statement.  Round 3's split codec was such asm and needed
 4 the split is plain C++ (wn_codec.h) and no asm result feeds an MFMA any more.  The audit still flags any asm VALU
 result that an MFMA reads earlier than two wait states behind it, should one come back.
 
+Third rule (round 4): a packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose op_sel takes the HIGH
+register of its src1 pair for the LOW lane -- what the compiler makes of two scalar operations that share a factor sitting
+in an odd register, e.g. the second word of a ds_read_b64 -- is not reliable on gfx950 next to matrix instructions:
+scripts/ubench/pk_opsel.hip gets ~11 % wrong results from `v_pk_fma_f32 vD, vA, v[p:p+1], vC op_sel:[0,1,0]` with an
+MFMA issued directly behind it (none with one instruction in between, none for op_sel_hi / plain forms / src2 selects), and
+a group-kernel build whose epilogue scales were read per block (compiler: 24 such instructions per kernel, no MFMA directly
+behind any of them) was not repeatable call to call until those instructions were replaced, in the compiler's assembly, by
+two v_fma_f32 on the same registers (profiles/r04_pk_opsel_hazard.txt).  The kernels keep such factors in registers of
+their own (wn_opaque, wn_codec.h); the audit flags every packed-fp32 instruction with a src1 high-for-low select.
+
     python scripts/audit_store_hazard.py            # compiles csrc/*.hip with -save-temps into a temp dir
 """
 import os, re, subprocess, sys, tempfile
@@ -74,6 +84,12 @@ def audit(path):
                 break
             states += int(s2.split()[1]) + 1 if s2.startswith('s_nop') else 1
             j += 1
+    # third rule: packed fp32 with the high register of src1 selected for the low lane
+    for i, (ln, s, k) in enumerate(ins):
+        if re.match(r'v_pk_(fma|mul|add)_f32\b', s):
+            m = re.search(r'\bop_sel:\[([01]),([01])', s)
+            if m and m.group(2) == '1':
+                bad.append((k, ln, s, ln, 'op_sel takes the high register of src1 for the low lane'))
     for i, (ln, s, k) in enumerate(ins):
         m = re.match(r'(buffer|global|scratch|flat)_store_dwordx[34]\s+(.*)', s)
         if not m:
@@ -109,7 +125,7 @@ def main():
     for s in srcs:
         d = os.path.join(tmp, s)
         os.makedirs(d)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', os.path.join(ROOT, 'include'), '-I', B.CSRC,
+        cmd = [hipcc, '--offload-arch=gfx950'] + B.CODEGEN_FLAGS + ['-fPIC', '-I', os.path.join(ROOT, 'include'), '-I', B.CSRC,
                '-save-temps', '-c', os.path.join(B.CSRC, s), '-o', 'x.o'] + os.environ.get('WN_EXTRA_FLAGS', '').split()
         procs.append((s, d, subprocess.Popen(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
     for s, d, p in procs:

@@ -19,16 +19,16 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 2 * 32))()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert lib.wn_dbg_gk_stamps(buf) == 0
-a = np.array(buf[:], dtype=np.uint64).reshape(8, 2, 32).astype(np.int64)
+a = np.array(buf[:], dtype=np.uint64).reshape(4, 4, 32).astype(np.int64)
 names = ['entry', 'prologue issued', 'prologue landed', 'barrier']
 for j in range(5):
     names += ['L%d K done' % j, 'L%d epilogue math done' % j, 'L%d barrier 1' % j, 'L%d outputs + image written' % j, 'L%d barrier 2' % j]
-print('# %s group, last launch of the call; cycles since entry (s_memtime); rows = stamps, columns = workgroup/wave' % which)
+print('# %s group, last launch of the call; cycles since entry (s_memtime); rows = stamps, columns = 4 workgroups x waves 0, 4, 8, 11' % which)
 r0 = a[:, :, 30].min()
-print('%-28s' % 'start (us after first, realtime)', ' '.join('%8.2f' % ((a[g, wv, 30] - r0) / 100.0) for g in range(8) for wv in range(2)))
-print('%-28s' % 'lifetime us (realtime)', ' '.join('%8.2f' % ((a[g, wv, 31] - a[g, wv, 30]) / 100.0) for g in range(8) for wv in range(2)))
+print('%-28s' % 'start (us after first, realtime)', ' '.join('%8.2f' % ((a[g, wv, 30] - r0) / 100.0) for g in range(4) for wv in range(4)))
+print('%-28s' % 'lifetime us (realtime)', ' '.join('%8.2f' % ((a[g, wv, 31] - a[g, wv, 30]) / 100.0) for g in range(4) for wv in range(4)))
 for k in range(1, 29):
     if k >= len(names): break
-    vals = [(a[g, wv, k] - a[g, wv, 0]) if a[g, wv, k] else -1 for g in range(8) for wv in range(2)]
+    vals = [(a[g, wv, k] - a[g, wv, 0]) if a[g, wv, k] else -1 for g in range(4) for wv in range(4)]
     print('%-28s' % names[k], ' '.join('%8d' % v for v in vals))
-print('%-28s' % 'end', ' '.join('%8d' % (a[g, wv, 29] - a[g, wv, 0]) for g in range(8) for wv in range(2)))
+print('%-28s' % 'end', ' '.join('%8d' % (a[g, wv, 29] - a[g, wv, 0]) for g in range(4) for wv in range(4)))

@@ -10,7 +10,7 @@ mkdir -p vlibs
 python -m nsynth_wavenet_amd.build > /dev/null
 for spec in "$@"; do
   tag=${spec%%=*}; flags=${spec#*=}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I include -I nsynth_wavenet_amd/csrc \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -I include -I nsynth_wavenet_amd/csrc \
       $flags -c nsynth_wavenet_amd/csrc/$base.hip -o vlibs/${base}_$tag.o &
 done
 wait

@@ -1,4 +1,4 @@
-"""The two gfx950 hazards hipcc does not guard, as known-answer programs on the device: the UNGUARDED
+"""The three gfx950 hazards hipcc does not guard, as known-answer programs on the device: the UNGUARDED
 instruction sequences must still go wrong and the guarded ones must be exact.  If a compiler / firmware / hardware
 revision changes either rule this test says so -- in both directions: a rule that no longer bites makes a guard
 removable, a guard that no longer suffices makes audio wrong.
@@ -53,3 +53,17 @@ def test_wide_store_data_overwritten_behind_the_store(tmp_path):
         warnings.warn('the unguarded wide-store sequence lost no word on this box: the gfx950 store hazard did not '
                       'reproduce -- re-check whether buf_st4 still needs its wait states (wn_mfma_h.h)')
     assert r['store2'][0] == 0, r
+
+
+def test_packed_fp32_with_a_high_for_low_select_goes_wrong_in_front_of_an_mfma(tmp_path):
+    """`v_pk_fma_f32 vD, vA, v[p:p+1], vC op_sel:[0,1,0]` -- both lanes multiply by the HIGH register of the src1 pair, what
+    the SLP vectorizer makes of two scalar FMAs that share a factor sitting in an odd register -- computes something else
+    about one time in nine when an MFMA of the wave is issued directly behind it; with one instruction slot in between,
+    or with the factor in the LOW register (op_sel_hi), it is exact (scripts/ubench/pk_opsel.hip has the other forms
+    tried).  A group-kernel build with 24 such instructions per kernel was not repeatable call to call although no MFMA
+    sat directly behind any of them (profiles/r04_pk_opsel_hazard.txt), so csrc/ is compiled with -fno-slp-vectorize
+    (build.py) and scripts/audit_store_hazard.py refuses the instruction form in every kernel."""
+    r = _run(tmp_path)
+    assert r['pksel0'][0] > 0.01 * r['pksel0'][1], r            # unguarded: measured ~11 % wrong
+    assert r['pksel1'][0] == 0, r                                # one slot between the packed instruction and the MFMA
+    assert r['pklow0'][0] == 0, r                                # low register for both lanes, MFMA directly behind
