@@ -66,14 +66,19 @@ typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
 // blocks in lock step: profiles/r04_epilogue_cost.txt).  And the compiler SEES these producers: the wait states
 // gfx950 needs between a VALU write and an MFMA that reads the register (scripts/ubench/valu_to_mfma.hip) are inserted
 // by its hazard recognizer for every consumer, present and future -- the use-site fences the asm form needed are gone.
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
 __device__ inline void wn_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-    // The hi word is PACKED from the two scalar conversions the lo halves are computed against.  (Written as a vector
-    // {(_Float16)x0, (_Float16)x1}, the compiler -- without the SLP vectorizer, build.py -- converts twice: a packed
-    // v_cvt_pk_f16_f32 for the word and scalar v_cvt_f16_f32 for the differences, and the two do not agree on fp16
-    // denormals: hi + lo was then off by up to 6e-5 for small values, 100 times the codec's error.)
-    const _Float16 hx = (_Float16)x0, hy = (_Float16)x1;
-    const wn_h2 l = {(_Float16)(x0 - (float)hx), (_Float16)(x1 - (float)hy)};
-    hi = __builtin_amdgcn_perm((unsigned)__builtin_bit_cast(unsigned short, hy), (unsigned)__builtin_bit_cast(unsigned short, hx), 0x05040100u);   // one v_perm_b32
+    // All in two-element vectors, so that the hi word is converted ONCE, packed (v_cvt_pk_f16_f32), and the lo halves are
+    // computed against the halves of that very word.  (With scalar conversions in the source the compiler -- without the
+    // SLP vectorizer, build.py -- converts twice: packed for the word, scalar v_cvt_f16_f32 for the differences, and the
+    // two instructions do not agree on fp16 denormals: hi + lo was then off by up to 6e-5 for small values, 100 times
+    // the codec's error; tests/test_gpu_teacher.py caught it.)
+    const wn_f2 x = {x0, x1};
+    const wn_h2 h = __builtin_convertvector(x, wn_h2);
+    const wn_f2 hf = __builtin_convertvector(h, wn_f2);
+    const wn_f2 d = {x0 - hf.x, x1 - hf.y};            // two scalar subtractions: a v_pk_add_f32 runs at half rate beside MFMAs
+    const wn_h2 l = __builtin_convertvector(d, wn_h2);
+    hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
 
