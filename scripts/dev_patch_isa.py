@@ -19,6 +19,23 @@ elif name == 'pknop':
         n[0] += 1
         return '\ts_nop 7\n\ts_nop 7\n' + m.group(0)
     dev = re.sub(r'\tv_pk_fma_f32 [^\n]* op_sel:\[0,1,0\]', f, dev)
+elif name.startswith('keep'):
+    # every high-for-low v_pk_fma_f32 replaced EXCEPT those of one (previous opcode, next opcode) class: which surroundings fail?
+    lines = dev.split('\n')
+    real = [i for i, l in enumerate(lines) if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
+    classes = {}
+    for k, i in enumerate(real):
+        if re.match(r'\tv_pk_fma_f32 .* op_sel:\[0,1,0\]', lines[i]):
+            classes.setdefault((lines[real[k - 1]].split()[0], lines[real[k + 1]].split()[0]), []).append(i)
+    order = sorted(classes, key=lambda c: (-len(classes[c]), c))
+    keep = order[int(name[4:])]
+    print('classes:', [(c, len(classes[c])) for c in order], ' kept unpatched:', keep)
+    for c in order:
+        if c == keep:
+            continue
+        for i in classes[c]:
+            lines[i] = re.sub(r'\tv_pk_fma_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\] op_sel:\[0,1,0\]', pk_scalar, lines[i])
+    dev = '\n'.join(lines)
 elif name == 'none':
     pass
 else:

@@ -401,6 +401,30 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused'])
+def test_repeated_calls_are_bit_identical_at_full_size(precision):
+    """Six calls on the same inputs at the headline size (one utterance, 384 frames, 76 800 samples: 4 800 blocks x 60
+    layers of epilogues per call) give the same bits.  This is the property that exposed the third gfx950 hazard of
+    DESIGN.md section 3.7 -- a packed-fp32 operand form that went wrong in a fraction of a percent of the block
+    epilogues, differently in every call, while every result stayed within a few 1e-3 of the right one."""
+    from oracle import wavenet_np as O
+    cfgd = load_json('parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    w = O.synth_weights(hp, 'student', seed=1234, init='tf')
+    eng = _engine(cfgd, w, precision)
+    rs = np.random.RandomState(5)
+    mel = rs.uniform(0, 1, [1, 384, 80]).astype(np.float32)
+    noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [1, O.iaf_length(384, hp)]))
+    first = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
+    assert all(np.isfinite(v).all() for v in first.values())
+    for rep in range(5):
+        again = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
+        for k in first:
+            assert np.array_equal(first[k], _np(again[k])), (precision, rep, k)
+    assert eng.range_fallbacks == 0
+    eng.close()
+
+
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 def test_resize_conv_upsampler(precision):
     """use_resize_conv=true (masked.py:294-322; disabled in the shipped JSONs but part of the config
