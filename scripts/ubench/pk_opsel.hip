@@ -15,6 +15,7 @@
 //   hipcc --offload-arch=gfx950 -O2 pk_opsel.hip -o pk_opsel && ./pk_opsel
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -32,6 +33,15 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
                  "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %6\n\tv_mov_b32 v110, %7\n\tv_mov_b32 v111, %8\n\t"                \
                  "s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\t" MF "\n\t" NOPS "\n\t" PKINSTR "\n\t"                                \
                  "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" E0 "\n\t" E1 "\n\t"                                                   \
+                 "v_mov_b32 %0, v106\n\tv_mov_b32 %1, v107"                                                                \
+                 : "=&v"(d0), "=&v"(d1), "=&v"(e0), "=&v"(e1) : "v"(lds_pair), "v"(c0), "v"(c1), "v"(a0), "v"(a1), "v"(a), "v"(b), "v"(gptr) \
+                 : "v100", "v101", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "memory")
+#define MF3 "v_mfma_f32_16x16x32_f16 v[114:117], %9, %10, 0\n\tv_mfma_f32_16x16x32_f16 v[114:117], %9, %10, v[114:117]\n\tv_mfma_f32_16x16x32_f16 v[114:117], %9, %10, v[114:117]"
+#define BODY3(NOPS, PKINSTR, E0, E1)                                                                                      \
+    asm volatile("ds_read_b64 v[100:101], %4\n\t"                                                                          \
+                 "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %6\n\tv_mov_b32 v110, %7\n\tv_mov_b32 v111, %8\n\t"                \
+                 "s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\t" MF3 "\n\t" NOPS "\n\t" PKINSTR "\n\t"                               \
+                 "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" E0 "\n\t" E1 "\n\t"                    \
                  "v_mov_b32 %0, v106\n\tv_mov_b32 %1, v107"                                                                \
                  : "=&v"(d0), "=&v"(d1), "=&v"(e0), "=&v"(e1) : "v"(lds_pair), "v"(c0), "v"(c1), "v"(a0), "v"(a1), "v"(a), "v"(b), "v"(gptr) \
                  : "v100", "v101", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "memory")
@@ -121,6 +131,34 @@ __device__ inline void body(float& d0, float& d1, float& e0, float& e1, unsigned
     if (FORM == 77) BODY("global_load_dwordx4 v[114:117], %11, off", NOMF, "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
     if (FORM == 78) BODY("global_load_dwordx4 v[114:117], %11, off", NOMF, "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel_hi:[1,0,1]", "v_fma_f32 %2, v110, v100, v104", "v_fma_f32 %3, v111, v100, v105");
     if (FORM == 79) BODY2("ds_read_b128 v[114:117], %4\n\tds_read_b128 v[114:117], %4 offset:16\n\tds_read_b128 v[114:117], %4 offset:32\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "s_waitcnt lgkmcnt(0)\n\tv_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 80) BODY3("s_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 81) BODY3("v_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 82) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 83) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 84) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 85) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 86) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 87) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 88) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 89) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 90) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 91) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 92) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 93) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 94) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 95) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 96) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 97) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 98) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 99) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 100) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 101) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 102) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 103) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 104) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 105) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 106) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
+    if (FORM == 107) BODY3("v_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\tv_add_u32 v112, v112, v113\n\ts_nop 0", "v_pk_fma_f32 v[106:107], v[110:111], v[100:101], v[104:105] op_sel:[0,1,0]", "v_fma_f32 %2, v110, v101, v104", "v_fma_f32 %3, v111, v101, v105");
 }
 template <int FORM>
 __global__ __launch_bounds__(512) void probe(const float* in, unsigned* bad, unsigned* stale, int iters) {
@@ -159,14 +197,14 @@ __global__ __launch_bounds__(512) void probe(const float* in, unsigned* bad, uns
     if (nstale) atomicAdd(stale, nstale);
     if (prev0 == 12345.f && prev1 == 1.f) bad[1] = 1;
 }
-int main() {
+int main(int argc, char** argv) {
     std::vector<float> in(1024);
     for (int i = 0; i < 1024; ++i) in[i] = 0.001f * (float)((i * 7919) % 1999) - 1.f;
     float* din;
     unsigned* dbad;
     (void)hipMalloc(&din, 4096); (void)hipMalloc(&dbad, 16);
     (void)hipMemcpy(din, in.data(), 4096, hipMemcpyHostToDevice);
-    const char* fn[80] = {"pk_fma  src1 = pair, op_sel:[0,1,0] (high for both)", "same, an MFMA of the wave issued in front", "pk_fma  src1 = pair, no selects (low, high)",
+    const char* fn[108] = {"pk_fma  src1 = pair, op_sel:[0,1,0] (high for both)", "same, an MFMA of the wave issued in front", "pk_fma  src1 = pair, no selects (low, high)",
                          "pk_fma  src1 = pair, op_sel_hi:[1,0,1] (low for both)", "pk_fma  src1 = pair, swapped (high, low)", "pk_mul  src1 = pair, op_sel:[0,1] (high for both)",
                          "pk_fma  src0 = pair, op_sel:[1,0,0] (high for both)", "pk_fma  src2 = pair, op_sel:[0,0,1] (high for both)",
                          "MFMA BEHIND: pk_fma src1 = pair, op_sel:[0,1,0]", "MFMA BEHIND: pk_fma src1 = pair, no selects", "MFMA BEHIND: pk_fma src1 = pair, op_sel_hi:[1,0,1]",
@@ -176,9 +214,9 @@ int main() {
                          "MFMA behind s_nop 0", "MFMA behind s_nop 3", "MFMA BEHIND: pk_fma src0 = pair, op_sel:[1,0,0]", "MFMA in FRONT: op_sel:[0,1,0]",
                          "another pk_fma op_sel:[0,1,0] BEHIND", "a pk_add BEHIND", "a ds_read_b128 BEHIND", "no MFMA of the wave, ANOTHER WAVE of the SIMD runs MFMAs",
                          "a pk_add behind, ANOTHER WAVE of the SIMD runs MFMAs",
-                         "MFMA in front, s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 1, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 2, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 3, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 4, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 5, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 6, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 7, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 8, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 9, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 10, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 11, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 12, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 13, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 14, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 15, then pk_fma op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 3, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 4, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 5, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 6, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 7, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 9, op_sel:[0,1,0]","src0 = MFMA rows, s_nop 5, two pk_fma + pk_add like the compiler","MFMA in front, 0 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 1 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 2 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 3 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 4 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 5 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 6 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 7 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 8 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 9 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 10 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 11 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 12 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 13 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 14 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 15 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 16 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 17 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 18 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 19 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 20 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 21 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 22 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 23 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 24 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]", "global loads in flight (returns at any time): op_sel:[0,1,0]", "global loads in flight: op_sel_hi:[1,0,1]", "LDS loads returning about now: op_sel:[0,1,0]"};
+                         "MFMA in front, s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 1, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 2, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 3, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 4, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 5, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 6, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 7, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 8, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 9, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 10, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 11, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 12, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 13, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 14, then pk_fma op_sel:[0,1,0]","MFMA in front, s_nop 15, then pk_fma op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 3, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 4, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 5, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 6, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 7, op_sel:[0,1,0]","src0 = rows of the MFMA in front, s_nop 9, op_sel:[0,1,0]","src0 = MFMA rows, s_nop 5, two pk_fma + pk_add like the compiler","MFMA in front, 0 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 1 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 2 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 3 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 4 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 5 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 6 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 7 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 8 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 9 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 10 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 11 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 12 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 13 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 14 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 15 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 16 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 17 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 18 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 19 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 20 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 21 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 22 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 23 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]","MFMA in front, 24 VALU instructions + s_nop 0, then pk_fma op_sel:[0,1,0]", "global loads in flight (returns at any time): op_sel:[0,1,0]", "global loads in flight: op_sel_hi:[1,0,1]", "LDS loads returning about now: op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 0 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 1 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 2 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 3 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 4 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 5 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 6 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 7 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 8 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 9 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 10 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 11 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 12 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 13 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 14 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 15 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 16 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 17 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 18 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 19 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 20 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 21 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 22 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 23 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 24 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 25 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 26 VALU instructions, then pk_fma op_sel:[0,1,0]","chain of 3 DEPENDENT MFMAs in front, 27 VALU instructions, then pk_fma op_sel:[0,1,0]"};
     const int iters = 4000;
-    for (int form = 0; form < 80; ++form) {
+    for (int form = (argc > 1 ? atoi(argv[1]) : 0); form < 108; ++form) {
         (void)hipMemset(dbad, 0, 16);
         if (form == 0) probe<0><<<256, 256>>>(din, dbad, dbad + 2, iters);
         if (form == 1) probe<1><<<256, 256>>>(din, dbad, dbad + 2, iters);
@@ -260,6 +298,34 @@ int main() {
         if (form == 77) probe<77><<<256, 256>>>(din, dbad, dbad + 2, iters);
         if (form == 78) probe<78><<<256, 256>>>(din, dbad, dbad + 2, iters);
         if (form == 79) probe<79><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 80) probe<80><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 81) probe<81><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 82) probe<82><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 83) probe<83><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 84) probe<84><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 85) probe<85><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 86) probe<86><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 87) probe<87><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 88) probe<88><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 89) probe<89><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 90) probe<90><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 91) probe<91><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 92) probe<92><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 93) probe<93><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 94) probe<94><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 95) probe<95><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 96) probe<96><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 97) probe<97><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 98) probe<98><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 99) probe<99><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 100) probe<100><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 101) probe<101><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 102) probe<102><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 103) probe<103><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 104) probe<104><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 105) probe<105><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 106) probe<106><<<256, 256>>>(din, dbad, dbad + 2, iters);
+        if (form == 107) probe<107><<<256, 256>>>(din, dbad, dbad + 2, iters);
         unsigned r[4];
         (void)hipMemcpy(r, dbad, 16, hipMemcpyDeviceToHost);
         printf("%-58s wrong: %9u of %ld   (low lane = product with the LOW register, high lane right: %u)\n", fn[form], r[0], 256L * 256 * iters, r[2]);
