@@ -130,7 +130,8 @@ int wn_abi_version(void);
  * width <= 416 (one tile of the generic layer kernel must fit the 160 KB of LDS) / deconv_width % 64 == 0 /
  * num_stages >= 3 on generic fp32 kernels (same results, much slower).
  * Teachers: 3 * width + deconv_width <= 2048 runs on the tuned step kernels (every shipped wavenet_*.json), up to 4096 on
- * a wide instantiation of the same kernels (one utterance at a time: a correctness path); beyond that wn_create refuses. */
+ * a wide instantiation of the same kernels (a correctness path: below four utterances, and at every batch size when
+ * 3*width + deconv_width + gate_width/2 > 3072, one utterance at a time; otherwise the batched step); beyond that wn_create refuses. */
 int wn_create(const wn_config* cfg_host, wn_handle** out);
 
 /* Provide one variable under its TensorFlow name WITHOUT the
@@ -272,11 +273,7 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
 /* wn_ar_generate replays the step from a hipGraph (16 steps per graph) when the caller's stream can be
  * captured (any stream but the legacy null stream); enable = 0 makes it issue plain launches instead
  * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  A failed capture falls back to
- * plain launches by itself and never leaves the caller's stream in capture mode.
- * Environment WN_AR_PERSIST=1 (opt-in, measured slower than the launches: DESIGN.md 3.4) selects the persistent
- * single-launch step for batches below 4; in that mode wn_ar_generate BLOCKS (it ends in a stream synchronise and
- * reads an error word back) and returns WN_EIO when a hand-off timed out.  A configuration the persistent kernel
- * cannot hold (width + skip + gate > 5 * min(CUs, width), e.g. wavenet_ce.json) silently keeps the per-layer launches. */
+ * plain launches by itself and never leaves the caller's stream in capture mode. */
 int wn_ar_set_graph(wn_handle* h, int enable);
 
 /* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher
@@ -299,8 +296,14 @@ int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 /* 1 when wn_iaf_generate(B, F) runs the residual layers in layer groups (up to five layers per launch with the residual
  * stream in LDS: one natural and one decimated group per ten-layer dilation cycle) -- the default of the hoisted form for
  * small calls (up to four utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
- * (or layer pair) is a launch of its own.  Environment WN_GROUPS=1 / WN_NO_GROUPS=1 force either. */
+ * (or layer pair) is a launch of its own. */
 int wn_iaf_layer_groups(const wn_handle* h, int B, int F);
+
+/* Launch structure of the hoisted form for this handle: mode 1 = layer groups at every call size they support, -1 = never
+ * (one launch per layer or layer pair), 0 = the size policy above.  The environment variables WN_GROUPS=1 /
+ * WN_NO_GROUPS=1 are read ONCE, in wn_create, as the initial mode; cross-form tests and A/B runs use this setter on a
+ * live handle.  Returns WN_EINVAL for any other mode. */
+int wn_iaf_set_groups(wn_handle* h, int mode);
 
 /* Measurement aid used by bench.py (not part of the reference's surface, not
  * thread-safe).  Between begin and end, wn_iaf_generate records a hipEvent pair

@@ -38,17 +38,12 @@ struct ArDims {
 
 // State blob (floats): [hdr 64][a_prev B][u ring 4*B][rings...][l B*W][s B*S][g B*G/2][z B*S][out B*OW][ebuf B*OW]
 struct ArStateLayout {
-    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, encT, slab, l2, dbuf, xch, total;
+    size_t a_prev, uring, rings, l, s, g, z, out, ebuf, encT, slab, l2, dbuf, total;
     int NB;      // 0: GEMV layout [batch][feature]; >0: MFMA layout [feature][NB] (NB = padded batch)
 };
 
 // The batched (MFMA) step keeps activations feature-major / batch-minor so that the batch is
 // the N dimension of v_mfma_f32_16x16x4_f32: one pass over the weights serves every utterance.
-// pairs of the exchange region: d [2][B][G] | lin [2][B][W] | s [B][S] | z [B][S] | out [B][OW'] | a [B'] (primed: even)
-__host__ __device__ inline int arp_pairs(int B, int W, int S, int G, int OW) {
-    return 2 * B * G + 2 * B * W + 2 * B * S + B * ((OW + 1) & ~1) + ((B + 1) & ~1);
-}
-
 // rows of the GEMV step past the default register tiles (AR_NCA / AR_NCH chunks of 256 floats): the wide instantiation
 static bool ar_wide(const wn_config& c) {
     return 3 * c.width + c.deconv_width > 2048 || c.gate_width / 2 > 1024 || c.width > 1024;
@@ -84,21 +79,13 @@ ArStateLayout ar_state_layout(const wn_handle* h, int B) {
     // merged GEMV step: second residual-stream buffer and two pre-activation buffers (ping-pong per layer)
     L.l2 = carve(Bp * c.width);
     L.dbuf = carve(L.NB ? 0 : 2 * (size_t)B * c.gate_width);
-    // persistent step (ar_persist_kernel): tagged (value, tag) pairs of everything workgroups hand to each other
-    L.xch = carve(L.NB ? 0 : 2 * (size_t)arp_pairs(B, c.width, c.skip_width, c.gate_width, c.out_width) + 16 + 8 * 16);
     L.total = o;
     return L;
 }
 
+// wave-wide sum, partners 32, 16, 8, 4, 2, 1; the four in-row steps are DPP moves instead of LDS permutes (a
+// ds_bpermute is ~100 cycles of latency, six in a row were 0.4 us of every layer launch of the one-utterance step)
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// the same tree as wave_sum (partners 32, 16, 8, 4, 2, 1 -- bit-identical sums) with the four in-row steps as DPP
-// moves instead of LDS permutes (a ds_bpermute is ~100 cycles of latency, six in a row were 0.4 us of every phase)
-__device__ inline float wave_sum_dpp(float v) {
     v += __shfl_xor(v, 32);
     v += __shfl_xor(v, 16);
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8 == xor 8
@@ -203,8 +190,10 @@ constexpr int AR_NCA = 8;    // chunks of the dilated + cond row: 3W + Cd <= 204
 constexpr int AR_NCH = 4;    // chunks of an H-long row (gate_width / 2 <= 1024)
 constexpr int AR_GEMV_MAXB = 3;   // the GEMV step serves batches below 4 (ar_padded_batch)
 // Wide teachers (masked.py takes any width): the same kernels with rows of up to 4096 / 2048 floats in registers and one
-// utterance at a time (three utterances' inputs beside a 4096-float row would not fit the register file); such shapes have
-// no batched pack (AR_MAXSLAB), so this instantiation serves every batch size -- a correctness path, like wn_iaf_x.hip
+// utterance at a time (three utterances' inputs beside a 4096-float row would not fit the register file).  Shapes whose
+// batched K = 3W + Cd + G/2 exceeds 256 * AR_MAXSLAB have no batched pack and take this instantiation at every batch size;
+// the others (e.g. width 640 with a double gate: K = 2816) switch to the batched MFMA step from four utterances on, like
+// the tuned shapes (tests/test_gpu_ar.py::test_wide_teachers_run_on_the_wide_instantiation runs B = 5 and 17 on them)
 constexpr int AR_NCA_W = 16, AR_NCH_W = 8, AR_GEMV_MAXB_W = 1;
 
 // sigmoid(a) * tanh(b) with the hardware exp / rcp (abs error ~1e-7, as in the IAF kernels)
@@ -868,496 +857,6 @@ void ar_enqueue_step_b(wn_handle* h, float* state, const ArStateLayout& L, const
                        per_step, Tn, idx, wav, out_params);
 }
 
-// =====================  persistent step (B < 4): ONE launch for many steps (opt-in, WN_AR_PERSIST=1)  =====================
-// The merged GEMV step above is 34 dependent launches of ~5.6 us (191 us per step at one utterance, hipGraph or not):
-// what a step costs is the number of launch boundaries.  Here the same 34 phases run inside ONE kernel that stays
-// resident (one workgroup of five waves per CU, launched cooperatively) for hundreds of steps:
-//   * row r of the [res | skip | d] row space of a layer (<= 5 NWG rows) belongs to wave (r / NWG, workgroup r % NWG) in EVERY phase,
-//     so a skip row's running sum never leaves its owner's registers and the weights of the wave's row for the next
-//     phase (and its ring / enc inputs, which are older than the phase) are requested BEFORE it waits for the previous
-//     phase -- the wait hides the weight stream;
-//   * what a phase hands to the next one (d_j, lin_j; s, z, out, the sample) is written as (value, tag) pairs with one
-//     8-byte write-through store each and read by polling the pairs themselves with 16-byte sc1 loads until every
-//     tag equals base + step * phases + phase: data and "ready" flag are the same word, ONE memory round trip per
-//     phase instead of store-ack + flag + poll + load (the R1 hand-off of the CDNA4 guide, write-once per tag);
-//   * ring pushes are plain write-through stores read a step or more later; every workgroup counts itself done once
-//     its stores of the step are acknowledged, and the sampling workgroup publishes the sample only after all have;
-//   * every spin is bounded: a timeout raises the error word, all workgroups leave, wn_ar_generate reports it.
-// Same arithmetic and summation order per row as ar_first_m_kernel / ar_layer_m_kernel / ar_rows_kernel.
-// MEASURED (config 3, one utterance, -DWN_ARP_STAMPS=0 prints the phases): 200 us per step against 190 us for the
-// launches.  A phase costs ~6 us: the end-of-phase counter add becoming visible and being seen ~1.7 us (polling the
-// tagged pairs directly instead -- 256 workgroups x 8 KB per poll -- was slower: 227 us per step), the pair reads
-// 1.1 us, gate + row + reduction 1.2 us, workgroup barriers 0.5 us, stores becoming visible the rest.  Every hand-off
-// between XCDs goes through the memory side at ~1.1 us per round trip and a phase needs three of them in sequence:
-// the same price as a kernel boundary (1.7 us) plus the first loads of the next kernel.  Not the default.
-constexpr int ARP_THREADS = 320;
-constexpr int ARP_NW = ARP_THREADS / 64;
-constexpr int ARP_SC1 = 16;
-constexpr int ARP_OOB = (int)0x80000000;
-constexpr unsigned ARP_SPIN_LIMIT = 1u << 21;
-typedef __amdgpu_buffer_rsrc_t arp_rsrc_t;
-
-struct ArpLayer {
-    unsigned wd, bd, wrs, brs, wcomp, bm, ring;   // float offsets (blob; `ring` inside the state, per batch element)
-    int dil;
-};
-struct ArpArgs {
-    float* state;
-    ArStateLayout L;
-    ArDims D;
-    const float* blob;
-    const ArpLayer* layers;
-    int nlayers;
-    unsigned start_off, wss_off, bss_off, wo1_off, bo1_off, wo2_off, bo2_off;
-    const float* forced;
-    const float* enc;
-    int Tn;
-    const float* rnd;
-    int n_rand;
-    unsigned long long seed;
-    int* idx;
-    float* wav;
-    float* out_params;
-    int xv;                  // floats per batch element of the shared vector buffer (max(S, OW))
-};
-struct ArpRun {              // per launch
-    long long t0;            // first step of this launch (== the state's step counter)
-    unsigned base;           // tags already used by earlier launches on this state
-    unsigned done0;          // value of the per-step "stores acknowledged" counter at launch
-    unsigned done1;          // value of the end-of-step counter at launch (teacher forcing only)
-    int nsteps;
-};
-
-__device__ inline bool arp_failed(arp_rsrc_t rctl) {
-    return __builtin_amdgcn_readfirstlane((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, 0, 0, ARP_SC1)) != 0u;
-}
-// poll `npairs` tagged pairs starting at pair `pair0` (even) until every tag equals `tag`; values -> dst[0..npairs)
-__device__ inline bool arp_poll(arp_rsrc_t rx, arp_rsrc_t rctl, int pair0, int npairs, unsigned tag, float* dst) {
-    const int ng = (npairs + 1) >> 1;
-    for (int g0 = 0; g0 < ng; g0 += ARP_THREADS) {
-        const int g = g0 + (int)threadIdx.x;
-        const bool valid = g < ng, two = 2 * g + 1 < npairs;
-        const int off = valid ? (pair0 + 2 * g) * 8 : ARP_OOB;
-        wn_u4 v;
-        for (unsigned spins = 0;; ++spins) {
-            v = __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, ARP_SC1));
-            const bool ok = !valid || (v[1] == tag && (!two || v[3] == tag));
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-            if (spins > 32u) __builtin_amdgcn_s_sleep(1);
-            if ((spins & 1023u) == 1023u) {
-                if (arp_failed(rctl)) return false;
-                if (spins > ARP_SPIN_LIMIT) {
-                    __builtin_amdgcn_raw_buffer_store_b32(0xA000u + tag % 4096u, rctl, (threadIdx.x & 63) == 0 ? 0 : ARP_OOB, 0, ARP_SC1);
-                    return false;
-                }
-            }
-        }
-        if (valid) {
-            dst[2 * g] = __uint_as_float(v[0]);
-            if (two) dst[2 * g + 1] = __uint_as_float(v[2]);
-        }
-    }
-    return true;
-}
-__device__ inline void arp_put(arp_rsrc_t rx, int pair, float v, unsigned tag, int lane) {
-    __builtin_amdgcn_raw_buffer_store_b64((wn_u2){__float_as_uint(v), tag}, rx, lane == 0 ? pair * 8 : ARP_OOB, 0, ARP_SC1);
-}
-// [ring(t-2d) | ring(t-d) | (lin: LDS) | enc]: the ring words were written by other workgroups -> sc1 loads
-__device__ inline GateX<> arp_gate_x(arp_rsrc_t rst, size_t ring2, size_t ring1, const float* enc_t, int W, int Cd, int lane) {
-    GateX<> g;
-    const int K = 3 * W + Cd;
-#pragma unroll
-    for (int i = 0; i < AR_NCA; ++i) {
-        const int k = i * 256 + lane * 4;
-        if (k < 2 * W) {
-            const size_t o = k < W ? ring2 + k : ring1 + (k - W);
-            g.x[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rst, (int)(o * 4), 0, ARP_SC1));
-        } else {
-            g.x[i] = (k >= 3 * W && k < K) ? *reinterpret_cast<const f4*>(enc_t + (k - 3 * W)) : (f4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    return g;
-}
-
-#ifdef WN_ARP_STAMPS      // dev aid: s_memrealtime (10 ns) stamps of the layer phases of one step, workgroup WN_ARP_STAMPS
-__device__ unsigned long long wn_arp_stamp_buf[64][8];
-#define ARP_STAMP(j, k) do { if (i == 8 && wg == (WN_ARP_STAMPS) && tid == 0 && (j) < 64) wn_arp_stamp_buf[j][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ARP_STAMP(j, k) do {} while (0)
-#endif
-
-template <int NB>
-__global__ __launch_bounds__(ARP_THREADS, 1) void ar_persist_kernel(const ArpArgs* __restrict__ Ap, const ArpRun R) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];
-    // the call's constants live in device memory (as kernel arguments they pinned ~100 SGPRs and the kernel spilled)
-    const ArpArgs& A = *Ap;
-    const ArDims D = A.D;
-    const ArStateLayout& L = A.L;
-    constexpr int B = NB;
-    const int W = D.W, S = D.S, G = D.G, H = G / 2, Cd = D.Cd, OW = D.OW, K = 3 * W + Cd;
-    float* shd = sh;                                  // d_{j-1} [B][G]
-    float* shm = shd + NB * G;              // m [B][H]
-    float* shl = shm + NB * H;              // lin_{j-1} [B][W]
-    float* shx = shl + NB * W;              // s / z / out / a [B][xv]
-    float* she = shx + NB * A.xv;           // CE scratch [OW]
-    float* red = she + OW;                            // [256]
-    float* sel_val = red + 256;                       // [64]
-    ArpLayer* lay = reinterpret_cast<ArpLayer*>(sel_val + 64);   // [nlayers]: the layer table (scalar loads of it cost 0.7 us per phase)
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, NWG = gridDim.x;
-    float* state = A.state;
-    const int np = arp_pairs(B, W, S, G, OW);
-    const arp_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(state + L.xch, 0, np * 8, 0x00020000);
-    const arp_rsrc_t rctl = __builtin_amdgcn_make_buffer_rsrc(state + L.xch + 2 * (size_t)np, 0, 64 + 8 * 64, 0x00020000);
-    const arp_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)(L.total * 4), 0x00020000);
-    const int XD = 0, XL = XD + 2 * B * G, XS = XL + 2 * B * W, XZ = XS + B * S, XO = XZ + B * S, OWP = (OW + 1) & ~1,
-              XA = XO + B * OWP;
-    const int n = A.nlayers, PH = n + 4, RL = W + S + G;
-    const float* blob = A.blob;
-    float* ur = state + L.uring;
-    int row0 = w * NWG + wg;                          // my row of every phase
-    float u1[NB], u2[NB], sacc[NB];
-#pragma unroll
-    for (int e = 0; e < NB; ++e) {
-        u1[e] = ur[((R.t0 + 3) & 3) * B + e];
-        u2[e] = ur[((R.t0 + 2) & 3) * B + e];
-        sacc[e] = 0.f;
-    }
-    for (int q = tid; q < A.nlayers * (int)(sizeof(ArpLayer) / 4); q += ARP_THREADS)
-        reinterpret_cast<unsigned*>(lay)[q] = reinterpret_cast<const unsigned*>(A.layers)[q];
-    __syncthreads();
-    // phase barrier: every workgroup adds 1 to counter (wg & 7) at the end of every phase; phase gp may start once
-    // counter c shows nper(c) * gp.  Eight counters on eight cache lines: 32 atomics each, polled by ONE wave per
-    // workgroup with one 8-lane load -- the tagged pairs are then read once (the tags stay as the proof).
-    unsigned* cnt = reinterpret_cast<unsigned*>(state + L.xch) + 2 * (size_t)np + 16;
-    const unsigned nper = lane < 8 ? (unsigned)((NWG - lane + 7) / 8) : 0u;
-    auto phase_wait = [&](unsigned gp) -> bool {        // all threads call; true = proceed
-        bool ok = true;
-        if (w == 0) {
-            const unsigned need = nper * gp;
-            const int coff = lane < 8 ? 64 + 64 * lane : ARP_OOB;
-            for (unsigned spins = 0;; ++spins) {
-                // four polls in flight, ~0.15 us apart: the counters are sampled every 0.15 us instead of once per
-                // memory round trip (1.1 us)
-                const unsigned c0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, coff, 0, ARP_SC1);
-                __builtin_amdgcn_s_sleep(4);
-                const unsigned c1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, coff, 0, ARP_SC1);
-                __builtin_amdgcn_s_sleep(4);
-                const unsigned c2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, coff, 0, ARP_SC1);
-                __builtin_amdgcn_s_sleep(4);
-                const unsigned c3 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, coff, 0, ARP_SC1);
-                if (__builtin_amdgcn_ballot_w64(lane < 8 && (int)(c0 - need) < 0) == 0) break;
-                if (__builtin_amdgcn_ballot_w64(lane < 8 && (int)(c1 - need) < 0) == 0) break;
-                if (__builtin_amdgcn_ballot_w64(lane < 8 && (int)(c2 - need) < 0) == 0) break;
-                if (__builtin_amdgcn_ballot_w64(lane < 8 && (int)(c3 - need) < 0) == 0) break;
-                if ((spins & 255u) == 255u && (arp_failed(rctl) || spins > ARP_SPIN_LIMIT / 4)) {
-                    if (spins > ARP_SPIN_LIMIT / 4)
-                        __builtin_amdgcn_raw_buffer_store_b32(0xD000u + gp % 4096u, rctl, lane == 0 ? 0 : ARP_OOB, 0, ARP_SC1);
-                    ok = false;
-                    break;
-                }
-            }
-        }
-        return !__syncthreads_or(!ok);
-    };
-    auto phase_done = [&]() {
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt + 16 * (wg & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-
-    for (int i = 0; i < R.nsteps; ++i) {
-        const long long t = R.t0 + i;
-        const unsigned tag0 = R.base + 1u + (unsigned)i * (unsigned)PH;
-        const unsigned gp0 = ((unsigned)R.t0 + (unsigned)i) * (unsigned)PH;      // phases completed before this step
-        // keep the row addresses of all six phase bodies from being hoisted out of the step loop (they were: ~300
-        // loop-invariant address registers, spilled): the bases "change" every step as far as the compiler knows
-        asm volatile("" : "+s"(blob), "+s"(row0));
-        // ===================== phase 0: lin_0, skip_start, d_0 =====================
-        {
-            const ArpLayer l0 = lay[0];
-            const size_t ringb = L.rings + (size_t)B * l0.ring;
-            const size_t slot2 = (size_t)((t + 1) % (2 * l0.dil + 1)) * B, slot1 = (size_t)((t + l0.dil + 1) % (2 * l0.dil + 1)) * B;
-            RowW<AR_NCA> wd;
-            RowW<AR_NCH> ws;
-            GateX<> gx[NB];
-            float bias = 0.f;
-            auto fetch = [&](int row) {
-                if (row >= W && row < W + S) {
-                    ws = row_load<AR_NCH>(blob + A.wss_off + (size_t)(row - W) * W, W, lane);
-                    bias = blob[A.bss_off + row - W];
-                } else if (row >= W + S && row < RL) {
-                    const int r = row - W - S;
-                    wd = row_load<AR_NCA>(blob + l0.wd + (size_t)r * K, K, lane);
-                    bias = blob[l0.bd + r];
-#pragma unroll
-                    for (int e = 0; e < NB; ++e)
-                        gx[e] = arp_gate_x(rst, ringb + (slot2 + e) * W, ringb + (slot1 + e) * W,
-                                               A.enc + ((size_t)e * A.Tn + t) * Cd, W, Cd, lane);
-                }
-            };
-            fetch(row0);
-            // the audio sample fed back (fastgen.py:154: starts at 0)
-            float a[NB];
-            if (!A.forced && i > 0) {
-                if (!phase_wait(gp0)) return;
-                const bool ok = arp_poll(rx, rctl, XA, B, tag0 - 1u, shx);
-                if (__syncthreads_or(!ok)) return;
-            }
-            if (A.forced && i > 0) {
-                // teacher forcing: no sample ties step t to step t - 1, so a plain barrier does (every workgroup has
-                // finished step t - 1: its ring pushes are acknowledged and it has read every pair it needed)
-                bool ok = true;
-                const unsigned need = R.done1 + (unsigned)NWG * (unsigned)i;
-                for (unsigned spins = 0;; ++spins) {
-                    const unsigned c = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, 12, 0, ARP_SC1);
-                    if ((int)(__builtin_amdgcn_readfirstlane(c) - need) >= 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((spins & 1023u) == 1023u && (arp_failed(rctl) || spins > ARP_SPIN_LIMIT)) {
-                        if (spins > ARP_SPIN_LIMIT)
-                            __builtin_amdgcn_raw_buffer_store_b32(0xC000u, rctl, lane == 0 ? 0 : ARP_OOB, 0, ARP_SC1);
-                        ok = false;
-                        break;
-                    }
-                }
-                if (__syncthreads_or(!ok)) return;
-            }
-#pragma unroll
-            for (int e = 0; e < NB; ++e) {
-                a[e] = 0.f;
-                {
-                    if (A.forced) a[e] = t > 0 ? A.forced[(size_t)e * A.Tn + (t - 1)] : 0.f;
-                    else if (i > 0) a[e] = shx[e];
-                    else a[e] = t > 0 ? state[L.a_prev + e] : 0.f;
-                }
-            }
-            __syncthreads();                               // shx is free again
-            for (int q = tid; q < B * W; q += ARP_THREADS) {
-                const int e = q / W, c = q - e * W;
-                float ue = 0.f, u1e = 0.f, u2e = 0.f;
-#pragma unroll
-                for (int x = 0; x < NB; ++x)
-                    if (x == e) {
-                        ue = D.mu ? wn_mu_law_scaled(a[x]) : a[x];
-                        u1e = u1[x];
-                        u2e = u2[x];
-                    }
-                const float* wb = blob + A.start_off;
-                const float v = wb[3 * W + c] + wb[c] * u2e + wb[W + c] * u1e + wb[2 * W + c] * ue;
-                shl[q] = v;
-                if (wg == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rst,
-                        (int)((ringb + ((size_t)(t % (2 * l0.dil + 1)) * B + e) * W + c) * 4), 0, ARP_SC1);
-                    if (c == 0) ur[(t & 3) * B + e] = ue;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < NB; ++e) {
-                u2[e] = u1[e];
-                u1[e] = D.mu ? wn_mu_law_scaled(a[e]) : a[e];
-            }
-            __syncthreads();
-            if (row0 >= W && row0 < RL) {
-                const int row = row0;
-#pragma unroll
-                for (int e = 0; e < NB; ++e) {
-                    const float* lin = shl + (size_t)e * W;
-                    if (row < W + S) {
-                        sacc[e] = wave_sum_dpp(row_fma<AR_NCH>(ws, W, lane, [&](int, int k) {
-                            return *reinterpret_cast<const f4*>(lin + k); })) + bias;
-                    } else {
-                        const float v = wave_sum_dpp(row_fma<AR_NCA>(wd, K, lane, [&](int ii, int k) {
-                            return (k >= 2 * W && k < 3 * W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * W)) : gx[e].x[ii]; })) + bias;
-                        arp_put(rx, XD + e * G + (row - W - S), v, tag0, lane);
-                    }
-                }
-            }
-            phase_done();
-        }
-        // ===================== phases 1..n: layers (n: only the skip rows of the last layer) =====================
-        for (int j = 1; j <= n; ++j) {
-            const bool last = j == n;
-            const ArpLayer pv = lay[j - 1];
-            const ArpLayer lp = lay[last ? n - 1 : j];
-            const size_t ringb = L.rings + (size_t)B * lp.ring;
-            const size_t slot2 = (size_t)((t + 1) % (2 * lp.dil + 1)) * B, slot1 = (size_t)((t + lp.dil + 1) % (2 * lp.dil + 1)) * B;
-            RowW<AR_NCA> wd;
-            RowW<AR_NCH> wh;
-            GateX<> gx[NB];
-            float bias = 0.f;
-            auto fetch = [&](int row) {
-                if (row < W + S) {
-                    if (last && row < W) return;
-                    wh = row_load<AR_NCH>(blob + pv.wrs + (size_t)row * H, H, lane);
-                    bias = blob[pv.brs + row];
-                } else if (!last && row < RL) {
-                    const int r = row - W - S;
-                    wd = row_load<AR_NCA>(blob + lp.wd + (size_t)r * K, K, lane);
-                    wh = row_load<AR_NCH>(blob + lp.wcomp + (size_t)r * H, H, lane);
-                    bias = blob[lp.bm + r];
-#pragma unroll
-                    for (int e = 0; e < NB; ++e)
-                        gx[e] = arp_gate_x(rst, ringb + (slot2 + e) * W, ringb + (slot1 + e) * W,
-                                               A.enc + ((size_t)e * A.Tn + t) * Cd, W, Cd, lane);
-                }
-            };
-            ARP_STAMP(j, 0);
-            fetch(row0);
-            ARP_STAMP(j, 1);
-            if (!phase_wait(gp0 + (unsigned)j)) return;
-            ARP_STAMP(j, 2);
-            bool ok = arp_poll(rx, rctl, XD + ((j - 1) & 1) * B * G, B * G, tag0 + (unsigned)(j - 1), shd);
-            if (ok && j >= 2 && !last) ok = arp_poll(rx, rctl, XL + ((j - 1) & 1) * B * W, B * W, tag0 + (unsigned)(j - 1), shl);
-            if (__syncthreads_or(!ok)) return;
-            ARP_STAMP(j, 3);
-            for (int q = tid; q < B * H; q += ARP_THREADS) {      // gate of the previous layer (wavenet.py:479)
-                const int e = q / H, k = q - e * H;
-                shm[q] = ar_gate(shd[e * G + k], shd[e * G + H + k]);
-            }
-            __syncthreads();
-            if (row0 < (last ? W + S : RL) && !(last && row0 < W)) {
-                const int row = row0;
-#pragma unroll
-                for (int e = 0; e < NB; ++e) {
-                    const float* m = shm + (size_t)e * H;
-                    const float* lin = shl + (size_t)e * W;
-                    if (row < W + S) {
-                        const float v = wave_sum_dpp(row_fma<AR_NCH>(wh, H, lane, [&](int, int k) {
-                            return *reinterpret_cast<const f4*>(m + k); })) + bias;
-                        if (row < W) {
-                            const float ln = lin[row] + v;                                        // wavenet.py:481-485
-                            arp_put(rx, XL + (j & 1) * B * W + e * W + row, ln, tag0 + (unsigned)j, lane);
-                            // lin_j is the INPUT of layer j: its queue slot of this step (masked.py:357-359)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ln), rst,
-                                lane == 0 ? (int)((ringb + ((size_t)(t % (2 * lp.dil + 1)) * B + e) * W + row) * 4) : ARP_OOB, 0, ARP_SC1);
-                        } else {
-                            sacc[e] += v;                                                     // wavenet.py:486-490
-                            if (last) arp_put(rx, XS + e * S + (row - W), sacc[e], tag0 + (unsigned)n, lane);
-                        }
-                    } else {
-                        float acc = row_fma<AR_NCA>(wd, K, lane, [&](int ii, int k) {
-                            return (k >= 2 * W && k < 3 * W) ? *reinterpret_cast<const f4*>(lin + (k - 2 * W)) : gx[e].x[ii]; });
-                        acc += row_fma<AR_NCH>(wh, H, lane, [&](int, int k) { return *reinterpret_cast<const f4*>(m + k); });
-                        arp_put(rx, XD + (j & 1) * B * G + e * G + (row - W - S), wave_sum_dpp(acc) + bias, tag0 + (unsigned)j, lane);
-                    }
-                }
-            }
-            if (j == n - 1 || (n == 1 && last)) {
-                // the last ring pushes of the step are out: count this workgroup done once they are acknowledged
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(state + L.xch) + 2 * (size_t)np + 2, 1u,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ARP_STAMP(j, 4);
-            phase_done();
-            ARP_STAMP(j, 5);
-        }
-        // ===================== out1: z = relu(Wo1 . [relu(s) | enc_t] + b) =====================
-        {
-            const int K1 = S + Cd;
-            RowW<AR_NCA> wo;
-            float bias = 0.f;
-            auto fetch = [&](int row) {
-                if (row < S) {
-                    wo = row_load<AR_NCA>(blob + A.wo1_off + (size_t)row * K1, K1, lane);
-                    bias = blob[A.bo1_off + row];
-                }
-            };
-            fetch(row0);
-            if (!phase_wait(gp0 + (unsigned)n + 1u)) return;
-            const bool ok = arp_poll(rx, rctl, XS, B * S, tag0 + (unsigned)n, shx);
-            if (__syncthreads_or(!ok)) return;
-            if (row0 < S) {
-                const int row = row0;
-#pragma unroll
-                for (int e = 0; e < NB; ++e) {
-                    const float* sv = shx + (size_t)e * S;
-                    const float* en = A.enc + ((size_t)e * A.Tn + t) * Cd;
-                    const float v = wave_sum_dpp(row_fma<AR_NCA>(wo, K1, lane, [&](int, int k) {
-                        f4 x = k < S ? *reinterpret_cast<const f4*>(sv + k) : *reinterpret_cast<const f4*>(en + (k - S));
-                        if (k < S) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.f);                  // wavenet.py:494
-                        }
-                        return x; })) + bias;
-                    arp_put(rx, XZ + e * S + row, fmaxf(v, 0.f), tag0 + (unsigned)n + 1u, lane);   // wavenet.py:499
-                }
-            }
-            phase_done();
-        }
-        // ===================== out2 =====================
-        {
-            RowW<AR_NCH> wo;
-            float bias = 0.f;
-            auto fetch = [&](int row) {
-                if (row < OW) {
-                    wo = row_load<AR_NCH>(blob + A.wo2_off + (size_t)row * S, S, lane);
-                    bias = blob[A.bo2_off + row];
-                }
-            };
-            fetch(row0);
-            if (!phase_wait(gp0 + (unsigned)n + 2u)) return;
-            const bool ok = arp_poll(rx, rctl, XZ, B * S, tag0 + (unsigned)n + 2u - 1u, shx);
-            if (__syncthreads_or(!ok)) return;
-            if (row0 < OW) {
-                const int row = row0;
-#pragma unroll
-                for (int e = 0; e < NB; ++e) {
-                    const float* zv = shx + (size_t)e * S;
-                    const float v = wave_sum_dpp(row_fma<AR_NCH>(wo, S, lane, [&](int, int k) {
-                        return *reinterpret_cast<const f4*>(zv + k); })) + bias;
-                    arp_put(rx, XO + e * OWP + row, v, tag0 + (unsigned)n + 2u, lane);
-                }
-            }
-            phase_done();
-        }
-        // ===================== sampling: workgroup b draws batch element b =====================
-        if (!phase_wait(gp0 + (unsigned)n + 3u)) return;
-        if (wg < B) {
-            const int b = wg;
-            const bool ok = arp_poll(rx, rctl, XO + b * OWP, OW, tag0 + (unsigned)n + 2u, shx);
-            if (__syncthreads_or(!ok)) return;
-            auto out = [&](int q) -> float { return shx[q]; };
-            if (A.out_params)
-                for (int q = tid; q < OW; q += ARP_THREADS) A.out_params[((size_t)b * A.Tn + t) * OW + q] = shx[q];
-            auto rnd_at = [&](int q) -> float { return ar_rnd_at(D, A.rnd, A.n_rand, A.seed, t, t, b, q); };
-            const int qs = ar_sample_q(D, out, rnd_at, she, red, sel_val, tid);
-            bool ok2 = true;
-            if (tid < 64) {
-                const float av = wn_dequant(__builtin_amdgcn_readfirstlane(qs), D.Q, D.mu);
-                if (tid == 0) {
-                    state[L.a_prev + b] = av;
-                    if (A.idx) A.idx[(size_t)b * A.Tn + t] = qs;
-                    if (A.wav) A.wav[(size_t)b * A.Tn + t] = av;
-                }
-                // every workgroup's stores of this step (ring pushes) are acknowledged before the sample goes out
-                const unsigned need = R.done0 + (unsigned)NWG * (unsigned)(i + 1);
-                for (unsigned spins = 0;; ++spins) {
-                    const unsigned c = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rctl, 8, 0, ARP_SC1);
-                    if ((int)(__builtin_amdgcn_readfirstlane(c) - need) >= 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((spins & 1023u) == 1023u && (arp_failed(rctl) || spins > ARP_SPIN_LIMIT)) {
-                        if (spins > ARP_SPIN_LIMIT)
-                            __builtin_amdgcn_raw_buffer_store_b32(0xB000u, rctl, tid == 0 ? 0 : ARP_OOB, 0, ARP_SC1);
-                        ok2 = false;
-                        break;
-                    }
-                }
-                if (ok2) arp_put(rx, XA + b, av, tag0 + (unsigned)n + 3u, lane);
-            }
-            if (__syncthreads_or(!ok2)) return;
-        }
-        phase_done();
-        if (A.forced) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(state + L.xch) + 2 * (size_t)np + 3, 1u,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (wg == 0 && tid == 0) *reinterpret_cast<long long*>(state) = R.t0 + R.nsteps;
-}
-
 void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, const float* forced,
                      const float* enc, int Tn, int per_step, const float* rnd, uint64_t seed, int* idx,
                      float* wav, float* out_params, hipStream_t st) {
@@ -1401,92 +900,6 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
         }
 }
 
-// ---- persistent step: eligibility, layer table, launches ----
-bool ar_persist_ok(const wn_handle* h, int B) {
-    // measured: 200 us per step against 190 us for the 34 launches -- a phase hand-off through the
-    // memory side (counter add + poll + pair reads, ~1.1 us per round trip) costs what a launch boundary costs, so
-    // the kernel is opt-in (WN_AR_PERSIST=1), kept parity-tested
-    const char* pe = getenv("WN_AR_PERSIST");
-    const bool off = !(pe && atoi(pe) != 0);
-    if (off || B > AR_GEMV_MAXB || ar_padded_batch(B, h->ar.wss_b_off != 0) != 0 || ar_wide(h->cfg)) return false;
-    const wn_config& c = h->cfg;
-    const int W = c.width, S = c.skip_width, G = c.gate_width, Cd = c.deconv_width, OW = c.out_width;
-    if ((W | S | Cd | (G / 2)) & 3) return false;                       // 16-byte operand chunks, even pair regions
-    if (S + Cd > 256 * AR_NCA || OW > 1024) return false;
-    const int nwg = std::min(h->num_cu, W);                               // every workgroup owns a res row of every layer
-    if (W + S + G > ARP_NW * nwg || OW > ARP_NW * nwg) return false;      // one row per wave and phase
-    int coop = 0;
-    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) != hipSuccess || !coop) return false;
-    return true;
-}
-
-int ar_persist_run(wn_handle* h, float* state, int B, const float* forced, const float* enc, int Tn, const float* rnd,
-                   uint64_t seed, int* idx, float* wav, float* out_params, hipStream_t st) {
-    const ArPack& P = h->ar;
-    const ArStateLayout L = ar_state_layout(h, B);
-    const ArDims D = ar_dims(h, B);
-    if (!h->arp_layers) {
-        std::vector<ArpLayer> tab;
-        for (const ArLayerPack& lp : P.layers)
-            tab.push_back(ArpLayer{(unsigned)lp.wd_off, (unsigned)lp.bd_off, (unsigned)lp.wrs_off, (unsigned)lp.brs_off,
-                                   (unsigned)lp.wcomp_off, (unsigned)lp.bm_off, (unsigned)lp.ring_off, lp.dilation});
-        WN_HIP(h, hipMalloc(&h->arp_layers, align_up(tab.size() * sizeof(ArpLayer), 256) + sizeof(ArpArgs)));
-        WN_HIP(h, hipMemcpy(h->arp_layers, tab.data(), tab.size() * sizeof(ArpLayer), hipMemcpyHostToDevice));
-    }
-    ArpArgs A;
-    A.state = state; A.L = L; A.D = D; A.blob = h->d_blob;
-    A.layers = reinterpret_cast<const ArpLayer*>(h->arp_layers);
-    A.nlayers = (int)P.layers.size();
-    A.start_off = (unsigned)P.start_off; A.wss_off = (unsigned)P.wss_off; A.bss_off = (unsigned)P.bss_off;
-    A.wo1_off = (unsigned)P.wo1_off; A.bo1_off = (unsigned)P.bo1_off; A.wo2_off = (unsigned)P.wo2_off; A.bo2_off = (unsigned)P.bo2_off;
-    A.forced = forced; A.enc = enc; A.Tn = Tn; A.rnd = rnd; A.n_rand = wn_ar_n_rand(h); A.seed = seed;
-    A.idx = idx; A.wav = wav; A.out_params = out_params;
-    A.xv = std::max(D.S, D.OW);
-    const int nwg = std::min(h->num_cu, D.W);
-    const size_t lds = ((size_t)AR_GEMV_MAXB * (D.G + D.G / 2 + D.W + A.xv) + D.OW + 256 + 64) * sizeof(float) +
-                       P.layers.size() * sizeof(ArpLayer);
-    const void* kern = B == 1 ? reinterpret_cast<const void*>(ar_persist_kernel<1>)
-                     : B == 2 ? reinterpret_cast<const void*>(ar_persist_kernel<2>)
-                              : reinterpret_cast<const void*>(ar_persist_kernel<3>);
-    if (lds > 64 * 1024) WN_HIP(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const char* ce = getenv("WN_AR_PERSIST_STEPS");
-    const int chunk = std::max(1, ce ? atoi(ce) : 512);
-    const unsigned PH = (unsigned)A.nlayers + 4u;
-    // the call's constants: behind the layer table in the same device buffer (stream-ordered upload)
-    ArpArgs* dA = reinterpret_cast<ArpArgs*>(reinterpret_cast<char*>(h->arp_layers) + align_up(P.layers.size() * sizeof(ArpLayer), 256));
-    WN_HIP(h, hipMemcpyAsync(dA, &A, sizeof(A), hipMemcpyHostToDevice, st));
-    for (int t0 = 0; t0 < Tn; t0 += chunk) {
-        ArpRun R;
-        R.t0 = t0;
-        R.base = (unsigned)t0 * PH;
-        R.done0 = (unsigned)nwg * (unsigned)t0;
-        R.done1 = forced ? (unsigned)nwg * (unsigned)t0 : 0u;
-        R.nsteps = std::min(chunk, Tn - t0);
-        void* args[] = {&dA, &R};
-        WN_HIP(h, hipLaunchCooperativeKernel(kern, dim3(nwg), dim3(ARP_THREADS),
-                                             args, (unsigned)lds, st));
-    }
-    // a hand-off that timed out raised the error word (every workgroup has left the kernel by then)
-    unsigned err = 0;
-    WN_HIP(h, hipMemcpyAsync(&err, state + L.xch + 2 * (size_t)arp_pairs(B, D.W, D.S, D.G, D.OW), sizeof(err),
-                             hipMemcpyDeviceToHost, st));
-    WN_HIP(h, hipStreamSynchronize(st));
-#ifdef WN_ARP_STAMPS
-    {
-        unsigned long long hb[64][8];
-        (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(wn_arp_stamp_buf), sizeof(hb));
-        fprintf(stderr, "arp stamps (us): phase | fetch issue | counter wait | pair reads | gate + row | done add | gap to next\n");
-        for (int j = 1; j <= A.nlayers && j < 63; ++j)
-            fprintf(stderr, "  %2d  %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f\n", j, (hb[j][1] - hb[j][0]) * 0.01, (hb[j][2] - hb[j][1]) * 0.01,
-                    (hb[j][3] - hb[j][2]) * 0.01, (hb[j][4] - hb[j][3]) * 0.01, (hb[j][5] - hb[j][4]) * 0.01,
-                    j < A.nlayers ? (hb[j + 1][0] - hb[j][5]) * 0.01 : 0.0);
-    }
-#endif
-    if (err) return wn_fail(h, WN_EIO, "wn_ar_generate: persistent step gave up waiting for a hand-off (code 0x%x); "
-                            "is another kernel occupying the GPU?  WN_AR_PERSIST=0 selects the per-layer launches", err);
-    return WN_OK;
-}
-
 struct ArGraphCache {
     hipGraphExec_t exec_multi = nullptr, exec_one = nullptr;
     hipGraph_t g_multi = nullptr, g_one = nullptr;
@@ -1508,10 +921,6 @@ void ar_cache_free(ArGraphCache* c) {
 void wn_ar_release(wn_handle* h) {
     ar_cache_free(reinterpret_cast<ArGraphCache*>(h->ar_graph_cache));
     h->ar_graph_cache = nullptr;
-}
-void wn_ar_free_tables(wn_handle* h) {
-    if (h->arp_layers) (void)hipFree(h->arp_layers);
-    h->arp_layers = nullptr;
 }
 
 // ---------------------------------------------------------------------------
@@ -1724,8 +1133,6 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* state = reinterpret_cast<float*>(ws);
     WN_HIP(h, hipMemsetAsync(state, 0, need, st));
-    if (ar_persist_ok(h, B) && h->ar_persist)
-        return ar_persist_run(h, state, B, forced_wav, enc, Tn, rnd, seed, idx, wav, out_params, st);
 
     auto plain = [&](int n) -> int {
         for (int t = 0; t < n; ++t)

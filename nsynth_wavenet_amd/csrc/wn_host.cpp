@@ -331,7 +331,6 @@ extern "C" const char* wn_last_error(const wn_handle* h) {
 extern "C" void wn_destroy(wn_handle* h) {
     if (!h) return;
     wn_ar_release(h);
-    wn_ar_free_tables(h);
     if (h->d_blob) (void)hipFree(h->d_blob);
     delete h;
 }

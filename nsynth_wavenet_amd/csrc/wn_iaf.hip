@@ -945,8 +945,15 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 // WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
-    if (h->groups_env) return h->groups_env > 0;                // WN_NO_GROUPS / WN_GROUPS, resolved once in wn_create
+    if (h->groups_env) return h->groups_env > 0;                // wn_iaf_set_groups; WN_NO_GROUPS / WN_GROUPS set its initial value in wn_create
     return (int64_t)B * ((T / 16 + 19) / 20) <= 4 * (int64_t)h->num_cu;
+}
+
+extern "C" int wn_iaf_set_groups(wn_handle* h, int mode) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_iaf_set_groups: null handle");
+    if (mode < -1 || mode > 1) return wn_fail(h, WN_EINVAL, "wn_iaf_set_groups: mode must be -1 (never), 0 (policy) or 1 (always), got %d", mode);
+    h->groups_env = mode;
+    return WN_OK;
 }
 
 extern "C" int wn_iaf_layer_groups(const wn_handle* h, int B, int F) {

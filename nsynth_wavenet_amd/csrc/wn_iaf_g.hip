@@ -33,13 +33,6 @@
 #include "wn_mfma_h.h"
 #include "wn_iaf_c.h"
 
-#ifdef GK_STAMPS
-// TEMPORARY timeline aid: s_memtime stamps of waves 0 and 11 of a few workgroups (dev builds only)
-__device__ unsigned long long gk_stamps[8 * 2 * 32];
-#define GK_STAMP(k) do { if (stamp_slot >= 0 && (k) < 30) stamp_base[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GK_STAMP(k) do { } while (0)
-#endif
 
 namespace {
 
@@ -129,14 +122,6 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
     const int RS16 = (int)A.RS * 16;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
     float amax = 0.f;
-#ifdef GK_STAMPS
-    // workgroups 0, 31, 62, 93, waves 0, 4, 8 (one SIMD's three) and 11
-    const int stamp_w = wave == 0 ? 0 : wave == 4 ? 1 : wave == 8 ? 2 : wave == GK_WAVES - 1 ? 3 : -1;
-    const int stamp_slot = (blockIdx.x % 31 == 0 && blockIdx.x / 31 < 4 && stamp_w >= 0 && lane == 0) ? (int)(blockIdx.x / 31) * 4 + stamp_w : -1;
-    unsigned long long* stamp_base = gk_stamps + (stamp_slot < 0 ? 0 : stamp_slot) * 32;
-    if (stamp_slot >= 0) { stamp_base[30] = __builtin_amdgcn_s_memrealtime(); stamp_base[29] = 0; }
-    GK_STAMP(0);
-#endif
 
     // zero block -1 of both planes (never written afterwards)
     if (threadIdx.x < 256)
@@ -247,13 +232,10 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         g_dma_image(A.L[0].w, lds_base + GK_A_OFF, LC_A_WORDS, wave, lane);
         g_dma_image(A.L[0].w + IAF_P_FLOATS, lds_base + GK_T_OFF, LC_TAIL_WORDS, wave, lane);
         load_c(A.L[0].C);
-        GK_STAMP(1);
         // the segment and the first image have landed (LDS-DMA the compiler does not track: an explicit wait); the eight tile
         // loads are the youngest requests of the wave and vmcnt retires in order, so they stay in flight across the barrier
         g_dma_wait_but<4 * GK_HN>();
-        GK_STAMP(2);
         __syncthreads();
-        GK_STAMP(3);
 
         for (int j = 0; j < A.nl; ++j) {
             const bool fin = j + 1 == A.nl;
@@ -316,7 +298,6 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     }
                 }
             }
-            GK_STAMP(4 + 5 * j);
             bool on[GK_HN];
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) on[e] = blk_of(e) >= A.L[j].first && active(blk_of(e));
@@ -367,13 +348,10 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                         buf_st4(ol[e][s2], ro, vo, (8 + 4 * s2) * RS16);
                     }
                 }
-                GK_STAMP(5 + 5 * j);
                 continue;
             }
-            GK_STAMP(5 + 5 * j);
             __syncthreads();                               // every K loop has read this layer's input and fragments, every
                                                            // epilogue this layer's tail
-            GK_STAMP(6 + 5 * j);
             // in-place update of the wave's blocks (LAST: the head below reads its input from here) ...
 #pragma unroll
             for (int e = 0; e < GK_HN; ++e) {
@@ -393,9 +371,7 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
             }
             // ... and the staged tail
             if ((int)threadIdx.x < n_tail) *reinterpret_cast<wn_u4*>(lds + d_tail + threadIdx.x * 16) = stt;
-            GK_STAMP(7 + 5 * j);
             __syncthreads();                               // layer output and next image in LDS
-            GK_STAMP(8 + 5 * j);
         }
 
         if (LAST) {
@@ -459,20 +435,11 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
         }
     }
     wn_range_flag(amax, A.status);
-#ifdef GK_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (stamp_slot >= 0) { stamp_base[29] = __builtin_amdgcn_s_memtime(); stamp_base[31] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }
 
 
 }  // namespace
 
-#ifdef GK_STAMPS
-extern "C" int wn_dbg_gk_stamps(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gk_stamps), sizeof(unsigned long long) * 8 * 2 * 32);
-}
-#endif
 
 int wn_iaf_g_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_group_kernel<false, false>),

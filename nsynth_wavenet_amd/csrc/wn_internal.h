@@ -151,8 +151,6 @@ struct wn_handle {
     // cached hipGraph for the AR step (wn_ar.hip)
     void* ar_graph_cache = nullptr;
     bool ar_use_graph = true;                 // wn_ar_set_graph
-    bool ar_persist = true;                   // persistent step kernel for B < 4 (wn_ar_set_persistent)
-    void* arp_layers = nullptr;               // its layer table on the device
     // bench.py measurement aid (wn_profile_begin/end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // begin/end pairs
@@ -266,7 +264,6 @@ std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, c
 size_t wn_iaf_workspace_bytes(const wn_handle* h, int B, int F, int form = WN_FORM_DEFAULT);
 size_t wn_ar_workspace_bytes(const wn_handle* h, int B, int F);
 void wn_ar_release(wn_handle* h);
-void wn_ar_free_tables(wn_handle* h);
 int wn_ar_post_upload(wn_handle* h);   // device-side part of the AR packing (composite matrices)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -235,6 +235,13 @@ class Engine(object):
         """True when iaf_generate(batch, num_frames) runs the residual layers in LDS-resident layer groups."""
         return bool(self.lib.wn_iaf_layer_groups(self._h, int(batch), int(num_frames)))
 
+    def set_layer_groups(self, mode):
+        """Launch structure of the hoisted form: True / 1 = layer groups wherever they apply, False / -1 = one launch per
+        layer (pair), None / 0 = the library's size policy (wn_iaf_set_groups)."""
+        m = 0 if mode is None else (1 if mode is True else -1 if mode is False else int(mode))
+        self._check(self.lib.wn_iaf_set_groups(self._h, m))
+        return self
+
     # ---- measurement aid (bench.py) ----
     def profile_begin(self):
         self._check(self.lib.wn_profile_begin(self._h))

@@ -14,8 +14,7 @@ for prec in ('f16x3', 'f16x3-fused'):
         noise = O.logistic_from_uniform(np.random.RandomState(2).uniform(1e-5, 1 - 1e-5, [B, T]), np.float32)
         ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
         for mode in ('groups', 'nogroups'):
-            os.environ.pop('WN_NO_GROUPS', None); os.environ.pop('WN_GROUPS', None)
-            os.environ['WN_NO_GROUPS' if mode == 'nogroups' else 'WN_GROUPS'] = '1'
+            eng.set_layer_groups(mode == 'groups')
             errs = []
             for rep in range(3):
                 a = eng.iaf_generate(mel, noise, want=('x',), check_range=False)['x'].cpu().numpy()

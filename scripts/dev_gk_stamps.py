@@ -1,4 +1,5 @@
-"""dev: timeline of the group kernel from a -DGK_STAMPS build (WN_LIB_PATH=vlibs/lib_stamps.so).  The stamp buffer holds the
+"""dev: timeline of the group kernel from a -DGK_STAMPS build (WN_LIB_PATH=vlibs/lib_stamps.so) of csrc/wn_iaf_g.hip with
+profiles/r05_group_kernel_stamps.patch applied (the instrumentation is not part of the shipped kernel).  The stamp buffer holds the
 LAST group launch of a call (the head group of the last flow, a decimated one) -- run with --flows to cut the student short."""
 import ctypes, json, os, sys
 import numpy as np, torch

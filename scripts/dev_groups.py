@@ -11,13 +11,13 @@ for B, F in ((1, 11), (2, 35), (1, 384)):
     T = O.iaf_length(F, hp)
     mel = np.random.RandomState(1).uniform(0, 1, [B, F, 80]).astype(np.float32)
     noise = O.logistic_from_uniform(np.random.RandomState(2).uniform(1e-5, 1 - 1e-5, [B, T]), np.float32)
-    os.environ.pop('WN_NO_GROUPS', None)
+    eng.set_layer_groups(True)
     a = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
     a = {k: v.cpu().numpy() for k, v in a.items()}
-    os.environ['WN_NO_GROUPS'] = '1'
+    eng.set_layer_groups(False)
     b = eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot'))
     b = {k: v.cpu().numpy() for k, v in b.items()}
-    os.environ.pop('WN_NO_GROUPS', None)
+    eng.set_layer_groups(None)
     for k in a:
         d = np.abs(a[k] - b[k])
         print(B, F, T, k, 'max diff', d.max(), 'finite', np.isfinite(a[k]).all(), 'first bad', (np.argwhere(d > 1e-4)[:3].tolist() if d.max() > 1e-4 else None), 'fallbacks', eng.range_fallbacks)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "wn_iaf_c.h"
+#include "pair_epilogue_n.h"
 
 #ifndef EPI_VARIANT
 #define EPI_VARIANT 0

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "wn_iaf_c.h"
+#include "pair_epilogue_n.h"
 
 #ifndef NB
 #define NB 3

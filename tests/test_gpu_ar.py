@@ -260,43 +260,6 @@ def test_graph_replay_matches_plain_launches_and_inputs_are_checked(B):
     eng.close()
 
 
-@pytest.mark.parametrize('tag', ['ar_mol', 'ar_ce_mulaw', 'ar_gauss'])
-def test_persistent_step_kernel_matches_the_launched_step(tag, monkeypatch):
-    """WN_AR_PERSIST=1 (ar_persist_kernel: all phases of a step inside one cooperative launch, phase hand-offs as
-    tagged pairs) against the default 34-launch step on the golden cases: the golden K1 values and the launched
-    step's network outputs under teacher forcing (fp32 summation order of the two output layers differs: 2e-6 of the
-    range), the same samples free-running with injected randoms (a sample may flip where the draw sits on a
-    quantisation boundary, after which the two runs are different signals), reproducible bit for bit; twice in a
-    row on one engine (tags and counters keep counting across calls)."""
-    from oracle import wavenet_np as O
-    from nsynth_wavenet_amd.engine import Engine
-    g = np.load(os.path.join(GOLD, tag + '.npz'))
-    cfgd = json.loads(str(g['cfg_json']))
-    hp = O.HP(cfgd)
-    w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
-    eng = Engine(cfgd).load_weights(w)
-    monkeypatch.delenv('WN_AR_PERSIST', raising=False)
-    ref_f = _np(eng.ar_generate(g['enc'], g['rnd'], forced_wav=g['forced'], want_out=True)['out_params'])
-    ref = eng.ar_generate(g['enc'], g['rnd'], want_out=True)
-    ref_i, ref_o = _np(ref['idx']), _np(ref['out_params'])
-    monkeypatch.setenv('WN_AR_PERSIST', '1')
-    monkeypatch.setenv('WN_AR_PERSIST_STEPS', '7')             # several launches per call: counters carry over
-    for _ in range(2):
-        got_f = _np(eng.ar_generate(g['enc'], g['rnd'], forced_wav=g['forced'], want_out=True)['out_params'])
-        assert np.abs(got_f - g['out_forced']).max() <= 2e-5 * max(1.0, np.abs(g['out_forced']).max())
-        assert np.abs(got_f - ref_f).max() <= 2e-6 * max(1.0, np.abs(ref_f).max())
-        got = eng.ar_generate(g['enc'], g['rnd'], want_out=True)
-        gi = _np(got['idx'])
-        for b in range(gi.shape[0]):                              # per utterance: equal up to the first flipped sample
-            neq = np.nonzero(gi[b] != ref_i[b])[0]
-            t1 = int(neq[0]) if len(neq) else gi.shape[1]
-            assert t1 >= gi.shape[1] // 2 and (t1 == gi.shape[1] or abs(int(gi[b, t1]) - int(ref_i[b, t1])) <= 1)
-            assert np.abs(_np(got['out_params'])[b, :t1 + 1] - ref_o[b, :t1 + 1]).max() <= 2e-6 * max(1.0, np.abs(ref_o).max())
-        again = eng.ar_generate(g['enc'], g['rnd'], want_out=True)
-        assert np.array_equal(_np(again['idx']), gi) and np.array_equal(_np(again['out_params']), _np(got['out_params']))
-    eng.close()
-
-
 def test_teacher_configs_outside_the_kernel_limits_are_refused():
     """The AR step kernels hold one weight row in a register tile: 3*width + deconv_width <= 4096 (2048 on the tuned
     instantiation, the rest on the wide one), gate_width/2 <= 2048, 1 <= mol_mix <= 64 -- anything else must fail at
@@ -314,6 +277,7 @@ def test_teacher_configs_outside_the_kernel_limits_are_refused():
     dict(width=640, skip_width=512, double_gate_width=True),            # gate 1280: H = 640, d row 2176
     dict(width=1024, skip_width=256, deconv_width=512,                  # 3584-float rows, the widest class
          deconv_config=[[40, 10], [80, 20]]),
+    dict(width=256, skip_width=1536),                                   # narrow layers, out1 / out2 rows of 1792 / 1536 floats
 ])
 def test_wide_teachers_run_on_the_wide_instantiation(patch):
     """masked.conv1d / Fastgen.sample take any width (wavenet.py:326-345,379-514; masked.py:328-405).  Shapes whose weight
@@ -329,7 +293,7 @@ def test_wide_teachers_run_on_the_wide_instantiation(patch):
     eng = Engine(cfgd).load_weights(w)
     Cd = cfgd['deconv_width']
     rs = np.random.RandomState(1)
-    for B in (1, 3, 5):
+    for B in (1, 3, 5, 17):                     # 17: the batched pack of the shapes that have one, with two column tiles
         Tn = 32
         enc = (rs.standard_normal([B, Tn, Cd]) * 0.3).astype(np.float32)
         forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)

@@ -370,7 +370,8 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
     """The default hoisted form runs every dilation cycle as TWO launches of the layer-group kernel (wn_iaf_g.hip): a
     natural group (1, 2, 4, 8, 16) with its 62-sample causal halo recomputed per segment, and a decimated group
     (32 .. 512) on the 32 residue classes of time, with the start conv in a flow's first group and the flow head in
-    its last.  Held against the per-layer / layer-pair launches (WN_NO_GROUPS=1) on the same engine: same arithmetic,
+    its last.  Held against the per-layer / layer-pair launches on the same engine (wn_iaf_set_groups; the environment
+    switches are read once, in wn_create): same arithmetic,
     different summation partners only in the start conv -- on shapes with one segment, ragged last segments, one
     decimated block per residue, several utterances, the centre-crop variant, and private deconv stacks."""
     from oracle import wavenet_np as O
@@ -386,18 +387,19 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
             T = O.iaf_length(F, hp)
             mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
             noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
-            monkeypatch.delenv('WN_NO_GROUPS', raising=False)
-            monkeypatch.setenv('WN_GROUPS', '1')          # at any batch size (the default keeps it to small calls)
+            eng.set_layer_groups(True)                    # at any batch size (the default keeps it to small calls)
+            assert eng.iaf_layer_groups(B, F)             # ... so that the comparison cannot degenerate into a form against itself
             a = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
             a2 = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
-            monkeypatch.delenv('WN_GROUPS', raising=False)
-            monkeypatch.setenv('WN_NO_GROUPS', '1')
+            eng.set_layer_groups(False)
+            assert not eng.iaf_layer_groups(B, F)
             b = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
             for k in a:
                 assert np.isfinite(a[k]).all(), (extra, B, F, k)
                 assert np.array_equal(a[k], a2[k]), (extra, B, F, k)                      # deterministic
                 assert np.abs(a[k] - b[k]).max() <= 4e-6 * max(1.0, np.abs(b[k]).max()), (extra, B, F, k)
-        monkeypatch.delenv('WN_NO_GROUPS', raising=False)
+        with pytest.raises(ValueError):
+            eng.set_layer_groups(2)
         eng.close()
 
 

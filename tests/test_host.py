@@ -72,6 +72,47 @@ def test_compiled_kernels_are_free_of_the_hazards_hipcc_does_not_guard(tmp_path)
     assert r.stdout.count(' 0 finding(s)') >= 9
 
 
+def test_build_refuses_objects_that_contain_a_hazard(tmp_path):
+    """build() audits the DEVICE CODE of the objects it has just produced (llvm-objdump of the offload bundle) before it
+    links them -- the gate is on what ships, not on a second compile.  Negative test: crafted gfx950 objects, assembled
+    here with the ROCm assembler, each holding one of the three patterns, must be found by audit_object and must make
+    build.audit_objects raise; their guarded twins and the shipped objects must pass."""
+    import subprocess
+    from nsynth_wavenet_amd import build as wnbuild, hazard_audit
+    clang = hazard_audit.llvm_tool('clang')
+
+    def assemble(name, body):
+        src = tmp_path / (name + '.s')
+        src.write_text('\t.text\n\t.globl k\n\t.type k,@function\nk:\n' + body + '\ts_endpgm\n')
+        obj = tmp_path / (name + '.o')
+        subprocess.run([clang, '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', str(src), '-o', str(obj)],
+                       check=True, capture_output=True)
+        return str(obj)
+
+    bad = {
+        'store': '\tbuffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen\n\tv_max_f32_e64 v48, |v84|, |v85|\n',
+        'mfma': '\tv_add_f32_e32 v87, v51, v88\n\tv_mov_b32_e32 v88, v97\n\tv_mfma_f32_16x16x32_f16 v[100:103], v[80:83], v[84:87], v[60:63]\n',
+        'pk': '\tv_pk_fma_f32 v[14:15], v[14:15], v[86:87], v[82:83] op_sel:[0,1,0]\n',
+    }
+    good = {
+        'store_ok': '\tbuffer_store_dwordx4 v[48:51], v115, s[40:43], s75 offen\n\ts_nop 1\n\tv_max_f32_e64 v48, |v84|, |v85|\n',
+        'mfma_ok': '\tv_add_f32_e32 v87, v51, v88\n\ts_nop 1\n\tv_mfma_f32_16x16x32_f16 v[100:103], v[80:83], v[84:87], v[60:63]\n',
+        'pk_ok': '\tv_pk_fma_f32 v[14:15], v[14:15], v[70:71], v[82:83] op_sel_hi:[1,0,1]\n',
+    }
+    for name, body in bad.items():
+        obj = assemble(name, body)
+        assert len(hazard_audit.audit_object(obj)) == 1, name
+        with pytest.raises(RuntimeError, match='hazard audit failed'):
+            wnbuild.audit_objects([obj], verbose=False)
+    ok = [assemble(name, body) for name, body in good.items()]
+    wnbuild.audit_objects(ok, verbose=False)
+    # the objects of the shipped library (a hipcc offload bundle each): clean, and really disassembled
+    shipped = [os.path.join(wnbuild.LIB_DIR, os.path.splitext(s)[0] + '.o') for s in wnbuild.SOURCES]
+    wnbuild.audit_objects(shipped, verbose=False)
+    lst = hazard_audit.disassemble_object(os.path.join(wnbuild.LIB_DIR, 'wn_iaf_g.o'), str(tmp_path))
+    assert open(lst).read().count('v_mfma_f32_16x16x32_f16') > 1000
+
+
 def test_mel_entry_points_validate_arguments_before_touching_a_device():
     """wn_mel_frames is the reference's frame count (1 + n // 200, librosa centred frames, hop 12.5 ms);
     wn_mel_spectrogram refuses null pointers and signals that numpy.pad(reflect) would refuse (<= 1024 samples)."""

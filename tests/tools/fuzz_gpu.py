@@ -36,10 +36,10 @@ while time.time() < t_end:
         e = float((x - a['x']).abs().max())
         errs[p] = e if e == e else float('inf')
     # the hoisted form with the layer-group kernel forced on / off (the default picks by call size)
-    for tag, env in (('groups', 'WN_GROUPS'), ('per-layer', 'WN_NO_GROUPS')):
-        os.environ[env] = '1'
+    for tag, mode in (('groups', True), ('per-layer', False)):
+        engs['f16x3-hoisted'].set_layer_groups(mode)          # (the environment switches are read once, in wn_create)
         x = engs['f16x3-hoisted'].iaf_generate(mel, a['rand_input'], want=('x',))['x']
-        os.environ.pop(env)
+        engs['f16x3-hoisted'].set_layer_groups(None)
         e = float((x - a['x']).abs().max())
         errs[tag] = e if e == e else float('inf')
     tol = max(2e-5 * scale, 3.0 * errs['f32'])
