@@ -46,7 +46,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 BARRIER_KW = {}
 RED_DEV = None
-PROFILE_ROUND = 'r04'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
+PROFILE_ROUND = 'r05'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
 DOMINANT_KERNEL = 'iaf_group_kernel'    # layer groups at one / two utterances; 'iaf_layer_c_kernel' when every layer is a launch
 GROUP_LAYERS = 5                       # residual layers per launch of the group kernel (one half of a dilation cycle)
 # One 16-sample block of one residual layer on a gfx950 SIMD: 84 x v_mfma_f32_16x16x32_f16 = 1344 cycles of the matrix
@@ -83,7 +83,7 @@ def pmc_replay(B, F, precision='f16x3', hoisted=False, kernel=None):
             w = d['workload']
             if (w['batch_per_gpu'], w['frames']) == (B, F) and d.get('source_hash') == have:
                 k = d['kernels'][kernel]
-                return {'traffic': k['hbm_bytes_per_launch'], 'mfma_util': k.get('mfma_util'),
+                return {'traffic': k['hbm_bytes_per_launch'], 'mfma_util': k.get('mfma_util'), 'kernels': d['kernels'],
                         'kernel_us_per_call': d.get('kernel_us_per_call') or None, 'file': 'profiles/' + name}
         except (OSError, KeyError, ValueError):
             pass
@@ -133,6 +133,72 @@ def cpu_baseline(hp_dict, frames, budget_s=25.0):
                       'warm-up + median of {} runs; the reference TF path cannot run here'.format(
                           frames, T, max(len(times), 1)),
             'x_realtime': T / med / 16000.0}
+
+
+def teacher_extras(dev, ar_samples):
+    """`ar_b1`, `ar_b64`, `teacher_forward`: BASELINE.json configs[3] (wavenet_mol.json fastgen) at one and at 64 utterances and
+    Wavenet.feed_forward at 4.8 s, timed like bench_aux.py does (synthetic conditioning, random-init weights, Philox
+    sampling on the device).  One sample step of the AR path is a chain of dependent launches; its roofline is the
+    weight stream per step."""
+    from nsynth_wavenet_amd.engine import Engine
+    with open(os.path.join(ROOT, 'config_jsons', 'wavenet_mol.json')) as f:
+        hp = cfg.load_hparams(json.load(f))
+    eng = Engine(hp, kind='teacher', device=dev).load_weights(wts.synthetic_weights(hp, 'teacher', seed=1, init='unit'))
+    W, S, Cd = hp.width, hp.skip_width, hp.deconv_width
+    G = cfg.teacher_gate_width(hp)
+    OW = cfg.teacher_out_width(hp)
+    rs = np.random.RandomState(0)
+    out = {}
+    # weights streamed once per step (fp32): gate + composite, res/skip, head
+    wbytes = 4.0 * (hp.num_layers * (G * (3 * W + Cd) + (W + S) * (G // 2)) + (hp.num_layers - 1) * G * (G // 2) +
+                    S * W + S * (S + Cd) + OW * S)
+    mac_step = wbytes / 4.0
+    for B, key in ((1, 'ar_b1'), (64, 'ar_b64')):
+        Tn = ar_samples
+        enc = torch.as_tensor((rs.standard_normal([B, Tn, Cd]) * 0.1).astype(np.float32)).to(dev)
+        eng.ar_generate(enc[:, :64], None, seed=1, use_graph=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        o = eng.ar_generate(enc, None, seed=2, use_graph=False)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(o['wav']).all())
+        us_step = dt / Tn * 1e6
+        r = {'workload': 'BASELINE.json configs[3]: wavenet_mol.json autoregressive fastgen, {} utterance(s) x {} samples'.format(B, Tn),
+             'samples_per_sec': B * Tn / dt, 'us_per_sample_step': us_step, 'x_realtime_per_utterance': Tn / dt / 16000.0,
+             'x_realtime_aggregate': B * Tn / dt / 16000.0,
+             'launches_per_step': (hp.num_layers + 4) if B < 4 else (2 * hp.num_layers + 5), 'dtype': 'f32',
+             'bound': 'hbm', 'achieved': wbytes / (us_step * 1e-6) / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+             'frac': wbytes / (us_step * 1e-6) / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
+             'note': 'weight bytes streamed per sample step / step time; the step is a chain of dependent launches '
+                     '(launch-latency bound, DESIGN.md 3.4)'}
+        r.update(three_fracs(2.0 * mac_step * B, wbytes, us_step * 1e-6, 1, PEAK_F32_MFMA_TFLOPS))
+        out[key] = r
+    F = 384
+    T = F * cfg.frame_shift(hp)
+    mel = torch.as_tensor(rs.uniform(0, 1, [1, F, 80]).astype(np.float32)).to(dev)
+    wav = torch.as_tensor(rs.uniform(-1, 1, [1, T]).astype(np.float32)).to(dev)
+    for _ in range(2):
+        o = eng.teacher_forward(wav, mel)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        o = eng.teacher_forward(wav, mel)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 5
+    assert bool(torch.isfinite(o).all())
+    mac = hp.num_layers * (G * (3 * W + Cd) + (W + S) * (G // 2)) + S * W + S * (S + Cd) + OW * S
+    flop = 2.0 * mac * T
+    # activations a layer must move: l (3 taps read once when cached, written once), m, s read-modify-write, enc read
+    moved = 4.0 * T * (hp.num_layers * (2 * W + G // 2 + 2 * S + Cd)) + 4.0 * mac
+    r = {'workload': 'wavenet_mol.json Wavenet.feed_forward, 1 utterance of {} frames = {} samples'.format(F, T),
+         'samples_per_sec': T / dt, 'ms_per_call': dt * 1e3, 'x_realtime': T / dt / 16000.0,
+         'dtype': 'split-fp16 (3 fp16 MFMAs per product), fp32 accumulate', 'bound': 'mfma', 'achieved': flop / dt / 1e12,
+         'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flop / dt / 1e12 / PEAK_F16_MFMA_TFLOPS, 'traffic': None}
+    r.update(three_fracs(flop, moved, dt))
+    out['teacher_forward'] = r
+    eng.close()
+    return out
 
 
 def free_port():
@@ -218,6 +284,89 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
     return elapsed, layer_ms, layer_launches, wav
 
 
+def three_fracs(alg_flop, moved_bytes, seconds, mfma_per_product=3, peak_tf=PEAK_F16_MFMA_TFLOPS):
+    """The three fractions EVERY roofline block of this line carries, every round, so that blocks and rounds compare:
+    frac_mfma_alg   useful (algorithmic) FLOP/s over the dense MFMA peak of the arithmetic's instruction,
+    frac_mfma_exec  executed MFMA FLOP/s (x3 for the split-fp16 contraction: three fp16 MFMAs per product) over it,
+    frac_hbm_moved  bytes the launch(es) must move in THIS design (not SURVEY 8(d)'s per-layer model) over 8 TB/s."""
+    alg_tf = alg_flop / seconds / 1e12
+    return {'frac_mfma_alg': alg_tf / peak_tf, 'frac_mfma_exec': mfma_per_product * alg_tf / peak_tf,
+            'frac_hbm_moved': moved_bytes / seconds / 1e9 / PEAK_HBM_GBPS,
+            'algorithmic_TFLOPs': alg_tf, 'executed_TFLOPs': mfma_per_product * alg_tf, 'moved_GBps': moved_bytes / seconds / 1e9}
+
+
+def part_rooflines(eng, hp, B, F, T, part_us, pm):
+    """`roofline_cond` / `roofline_deconv`: the conditioning GEMM and the upsampler from the in-process part timing
+    (HIP events at the part boundaries, wn_profile_parts_*), with traffic / mfma_util of the committed PMC pass when it was
+    taken on these kernel sources."""
+    out = {}
+    f32 = eng.precision == 'f32'
+    npp, peak = (1, PEAK_F32_MFMA_TFLOPS) if f32 else (3, PEAK_F16_MFMA_TFLOPS)
+    kern = pm.get('kernels') or {}
+
+    def pmc_of(names):
+        tr = [kern[n]['hbm_bytes_per_launch'] for n in names if n in kern and kern[n].get('hbm_bytes_per_launch') is not None]
+        mu = {n: kern[n].get('mfma_util') for n in names if n in kern and kern[n].get('mfma_util') is not None}
+        return (sum(tr) if tr else None), (mu or None)
+
+    Cd, W = hp.deconv_width, hp.width
+    rows = W * (sum(hp.num_iaf_layers) + len(hp.num_iaf_layers))        # one 64-row block per layer and per flow head
+    stacks = 1 if getattr(hp, 'use_share_deconv', False) else len(hp.num_iaf_layers)
+    if part_us.get('cond_gemm'):
+        sec = part_us['cond_gemm'] * 1e-6
+        flop = 2.0 * rows * Cd * B * T
+        moved = 4.0 * rows * B * T + stacks * 4.0 * Cd * B * T + 4.0 * rows * Cd        # C written, enc read once per stack, weights
+        tr, mu = pmc_of(['iaf_cond_h_kernel'])
+        r = {'kernel': 'iaf_cond_h_kernel (wn_iaf_c.hip): C[{} x T] = Wcond[{} x {}] . enc, all layers and heads of a deconv stack in '
+                       'one GEMM, written in the accumulator layout of the layer kernels'.format(rows, rows, Cd),
+             'bound': 'mfma', 'achieved': flop / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': flop / sec / 1e12 / peak,
+             'us_per_call': part_us['cond_gemm'], 'launches_per_call': stacks, 'flop_per_call': flop,
+             'algorithmic_bytes_per_call': moved, 'traffic': tr, 'mfma_util': mu and mu.get('iaf_cond_h_kernel'),
+             'pmc_file': pm.get('file'),
+             'note': 'co-bound: its output alone (4 B x {} rows per sample) is {:.2f} GB per call, {:.0f} us at the ~5 TB/s '
+                     'this part sustains for writes'.format(rows, 4.0 * rows * B * T / 1e9, 4.0 * rows * B * T / 5e12 * 1e6)}
+        r.update(three_fracs(flop, moved, sec, npp, peak))
+        out['roofline_cond'] = r
+    if part_us.get('upsampler'):
+        sec = part_us['upsampler'] * 1e-6
+        flop, moved, L, cin = 0.0, 0.0, F, 80
+        nl = len(hp.deconv_config)
+        for j, (fl, st) in enumerate(hp.deconv_config):
+            Lout = L * st
+            taps = fl // st if not getattr(hp, 'use_resize_conv', False) else (fl - 1 + st - 1) // st + 1
+            flop += 2.0 * Cd * taps * cin * B * Lout
+            # input read once, weights once, output written once; intermediate layers still go through a phase-major fp32
+            # buffer (write + read), the last one writes its G4 words from the GEMM (deconv_pg_kernel, round 5)
+            moved += 4.0 * cin * B * L + 4.0 * Cd * taps * st * cin + 4.0 * Cd * B * Lout + (2 * 4.0 * Cd * B * Lout if j + 1 < nl else 0.0)
+            L, cin = Lout, Cd
+        flop *= stacks
+        moved *= stacks
+        names = ['deconv_mfma_h_kernel<false>', 'deconv_pg_kernel', 'deconv_mfma_hs_kernel<4>', 'deconv_interleave_g4_kernel', 'mel_to_split_kernel']
+        tr, mu = pmc_of(names)
+        r = {'kernel': 'upsampler (wn_deconv.hip): {} transposed-conv layers as per-phase split-fp16 GEMMs (deconv_mfma_h[s]_kernel) + '
+                       'phase interleave / fp16 split (deconv_interleave_g4_kernel)'.format(nl),
+             'bound': 'mfma', 'achieved': flop / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': flop / sec / 1e12 / peak,
+             'us_per_call': part_us['upsampler'], 'launches_per_call': stacks * 2 * nl, 'flop_per_call': flop,
+             'algorithmic_bytes_per_call': moved, 'traffic': tr, 'mfma_util': mu, 'pmc_file': pm.get('file')}
+        r.update(three_fracs(flop, moved, sec, npp, peak))
+        out['roofline_deconv'] = r
+    return out
+
+
+def measure_parts(eng, mel, rank, calls=10):
+    """Per-part microseconds of a generate call, measured in THIS process: HIP events at the part boundaries of `calls`
+    calls behind the timed region (each event costs the stream a few microseconds: the parts sum to slightly more than
+    the unprofiled call)."""
+    for i in range(2):
+        eng.iaf_generate(mel, None, seed=4000 + i, want=('wav',), check_range=False)
+    torch.cuda.synchronize()
+    eng.profile_parts_begin()
+    for i in range(calls):
+        eng.iaf_generate(mel, None, seed=5000 + 1000 * rank + i, want=('wav',), check_range=False)
+    ms, n = eng.profile_parts_end()
+    return {k: v * 1e3 / max(n, 1) for k, v in ms.items()}, n
+
+
 def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
     """Roofline record of the dominant kernel (the single-layer launches bracketed by HIP events inside the
     library, on the stream they are launched on)."""
@@ -247,8 +396,11 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
         mfma_floor_s = (B * T / 16) * nl * BLOCK_LAYER_MFMA_CYCLES / 1024 / clk
         roof = {'kernel': 'iaf_group_kernel (wn_iaf_g.hip: {} residual layers per launch on hoisted conditioning, l resident '
                           'in LDS, causal halo recomputed; natural and decimated groups alternate)'.format(nl),
-                'bound': 'mfma', 'achieved': executed_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': executed_tf / PEAK_F16_MFMA_TFLOPS,
+                'bound': 'mfma', 'achieved': executed_tf / 3, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': executed_tf / 3 / PEAK_F16_MFMA_TFLOPS,
+                'achieved_note': 'achieved / frac: ALGORITHMIC FLOP/s of the launch (halo recompute and the x3 of the split-fp16 '
+                                 'contraction not counted) over the dense fp16 MFMA peak; the matrix-pipe rate the launch '
+                                 'executes is executed_TFLOPs / frac_mfma_exec (round 4 printed that one under `frac`)',
                 'bound_note': 'SIMD issue per CU: matrix pipe + the VALU work beside it (gate, fp16 split / join); not HBM',
                 'layers_per_launch': nl,
                 'hbm_view': {'bytes_per_launch': bytes_per_launch, 'GBps': achieved_gbps, 'frac': achieved_gbps / PEAK_HBM_GBPS},
@@ -291,13 +443,16 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
                 'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                 'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
     pm = pmc_replay(B, F, eng.precision, hoisted, kernel_key)
+    f32 = eng.precision == 'f32'
+    roof.update(three_fracs(flops_per_launch, bytes_per_launch, avg_layer_s, 1 if f32 else 3,
+                            PEAK_F32_MFMA_TFLOPS if f32 else PEAK_F16_MFMA_TFLOPS))
     roof.update({'traffic': pm['traffic'], 'mfma_util': pm['mfma_util'], 'pmc_file': pm['file'],
                  'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass of this command on these kernel sources, '
                                  'profiles/; null when no such pass is committed)',
                  'algorithmic_bytes_per_launch': bytes_per_launch, 'flop_per_launch': flops_per_launch,
                  'avg_launch_us': avg_layer_s * 1e6, 'launches': layer_launches})
     if pm['kernel_us_per_call']:
-        roof['kernel_us_per_call'] = pm['kernel_us_per_call']     # rocprofv3 kernel trace of this command on these sources
+        roof['kernel_us_per_call_rocprof'] = pm['kernel_us_per_call']     # rocprofv3 kernel trace of this command on these sources (replayed)
     return roof
 
 
@@ -349,6 +504,8 @@ def main():
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
+    ap.add_argument('--ar-samples', type=int, default=1600,
+                    help='extras: generated samples per utterance of the autoregressive runs (configs[3]; 1600 = 0.1 s)')
     ap.add_argument('--ramp-steps', type=int, default=0,
                     help='extra untimed steps before the --warmup steps (clock ramp); 0 = exactly the protocol asked for')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
@@ -444,7 +601,19 @@ def main():
             },
             'roofline': roof,
         }
+    if rank == 0 and world == 1:
+        # Where the call's time goes, measured in THIS process (HIP events at the part boundaries of ten more calls) --
+        # not replayed from a profile -- and the roofline blocks of the two parts that are not the dominant kernel.
+        part_us, n_parts = measure_parts(eng, mel, rank)
+        eng.check_range()
+        rec['kernel_us_per_call'] = dict(part_us, calls=n_parts, source='HIP events at the part boundaries inside the library '
+                                         '(wn_profile_parts_*), this process, behind the timed region')
+        pm_all = pmc_replay(B, F, eng.precision, eng.iaf_cond_hoisted(B, F), rec['roofline'].get('kernel', '').split(' ')[0])
+        rec.update(part_rooflines(eng, hp, B, F, T, part_us, pm_all))
     if world == 1 and not args.no_extras:
+        # (0) the other BASELINE.json configs that fit one GPU, driver-timed in the same line: configs[3] (wavenet_mol.json
+        #     autoregressive fastgen, one utterance) and its batched form, and the teacher's full-sequence forward
+        rec.update(teacher_extras(dev, args.ar_samples))
         # (1) PCIe-inclusive call: pageable numpy mel in -> H2D -> generate -> D2H -> numpy wav out, the
         #     path of parallelgen.synthesis.  Reported beside the resident figure, never as `value`.
         n_e2e = max(3, min(args.steps, 20))

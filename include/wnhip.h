@@ -320,6 +320,16 @@ int wn_profile_begin(wn_handle* h);
 int wn_profile_pause(wn_handle* h, int paused);
 int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches);
 
+/* Second measurement mode, same caveats: between parts_begin and parts_end every wn_iaf_generate records one hipEvent on
+ * the caller's stream where a PART of the call begins -- 0: prologue + epilogue (pads, noise draw, final clip/quantise),
+ * 1: mel upsampler, 2: conditioning GEMM (hoisted form), 3: residual stack (start convs, layers / layer groups, flow
+ * heads).  parts_end synchronises and returns the summed milliseconds per part (part_ms[WN_PROFILE_PARTS]) and the
+ * number of calls recorded: bench.py's in-process replacement for a replayed rocprofv3 kernel trace.  Each event costs
+ * the stream a bubble of a few microseconds, so the sum of the parts is slightly above the unprofiled call time. */
+#define WN_PROFILE_PARTS 4
+int wn_profile_parts_begin(wn_handle* h);
+int wn_profile_parts_end(wn_handle* h, double* part_ms, int64_t* calls);
+
 /* Last error message of this handle (or of wn_create when h == NULL). */
 const char* wn_last_error(const wn_handle* h);
 

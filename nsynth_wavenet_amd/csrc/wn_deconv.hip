@@ -17,6 +17,7 @@
 #include "wn_internal.h"
 #include "wn_codec.h"
 #include "wn_pack_h.h"
+#include "wn_mfma_h.h"
 
 
 namespace {
@@ -420,6 +421,199 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_hs_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------
+// Phase-group GEMM (round 5): G4 words in, G4 words out -- no phase-major buffer, no interleave launch.
+//
+// Output sample t = S f + p (frame f, phase p) of a transposed conv is  y[t] = b + sum_j W[S j + r] . x[f + d - j]  with
+// r = (p + pL) % S, d = (p + pL) / S: every phase is a GEMM over (tap, channel) on the SAME frame axis f in [0, L), shifted
+// by d.  A wave tile is 8 MFMA row blocks x 5 column blocks of frames, the row blocks chosen so that a lane's accumulators
+// ARE finished G4 words at consecutive samples:
+//   full group  -- FOUR consecutive phases x 32 channels: rows 4 kg .. 4 kg + 3 of two 16-channel blocks = the four pair
+//                  slots of G4 group 4 s + kg, at four consecutive samples: four 16-byte stores per plane = 64 contiguous bytes;
+//   half group  -- TWO consecutive phases x 64 channels (where the phases of one d do not fill a group of four: with
+//                  S = 20, pL = 30 the phases split 10 | 10 = 4 + 4 + 2 each): two G4 groups x 32 contiguous bytes.
+// Every group has ONE d, so all row groups walk the same K = taps x cin and do the same work: (4 x 8 + 2 x 4) = 40 row
+// groups x 6 frame tiles of 640 = 240 workgroups at 4.8 s -- one round of one workgroup per CU, no tail.  Bias, activation,
+// fp16 split and the stores happen in the epilogue: the phase-major round trip (2 x 78.6 MB per utterance) and the
+// interleave launch (34 us) are gone.
+// Eight waves per workgroup (two per SIMD).  A lane owns 5 consecutive frames and loads, per 32-channel input block, the 8
+// words f - 3 .. f + 4 of its rows ONCE: tap m of frame e is register e + 3 - m, no shuffles.  The A fragments of a row
+// group (512 KB) stream through LDS by LDS-DMA, four K-steps (one input block) per stage, double buffered, shared by the
+// eight waves; row groups are laid out so that the tiles of one group run on one XCD (its L2 holds the group's fragments).
+constexpr int PG_TP = 4;                                 // taps (input columns per output frame and block)
+constexpr int PG_NT = 5;                                 // column blocks of 16 frames per wave
+constexpr int PG_WAVES = 8;
+constexpr int PG_FRAMES = PG_WAVES * 16 * PG_NT;         // 640 frames per workgroup
+constexpr int PG_KS_WORDS = 8 * 2 * 64 * 4;              // one K-step: 8 row blocks x 2 planes x 64 lanes x 4 words = 16 KB
+constexpr int PG_RG_WORDS_PER_BLOCK = PG_TP * PG_KS_WORDS;  // one LDS stage: the four taps of one input block = 64 KB
+constexpr int PG_LDS_BYTES = 2 * PG_RG_WORDS_PER_BLOCK * 4; // 128 KB
+constexpr int PG_MAXG = 8;                               // phase groups per layer
+
+struct PgArgs {
+    const unsigned* x;        // input, G4 rows [B][2][cin / 8][xs] x 16 B, frame f at column DC_XOFF + f
+    int cin, xs, L;
+    const unsigned* wp;       // phase-group pack (wn_pack_deconv): [row group][input block][tap][mb8][plane][lane][4]
+    const float* bias;
+    float inv_scale;
+    unsigned* y;              // output, G4 rows [B][2][cout / 8][ys] x 16 B, sample t at column yoff + t
+    int cout, S, act;
+    int64_t ys;
+    int yoff;
+    unsigned* status;
+    int ntiles;               // frame tiles per row group
+    int ngroups, nrg;         // phase groups, row groups
+    int g_p0[PG_MAXG], g_nph[PG_MAXG], g_d[PG_MAXG], g_rg0[PG_MAXG];   // first phase, phases (4 | 2), column offset, first row group
+};
+
+__device__ inline void pg_dma16(const unsigned* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
+__global__ __launch_bounds__(PG_WAVES * 64, 1) void deconv_pg_kernel(const PgArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned pg_lds[];
+    char* lds = reinterpret_cast<char*>(pg_lds);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    constexpr int NT = PG_NT, TP = PG_TP, NR = NT + TP - 1;
+    // blockIdx.x = (rg % 8) + 8 * ((rg / 8) * ntiles + tile): the tiles of a row group share an XCD
+    int rg, tile;
+    if ((A.nrg & 7) == 0) {
+        const int k = blockIdx.x >> 3;
+        rg = (blockIdx.x & 7) + 8 * (k / A.ntiles);
+        tile = k % A.ntiles;
+    } else {
+        rg = blockIdx.x / A.ntiles;
+        tile = blockIdx.x % A.ntiles;
+    }
+    int gi = 0;
+    for (int k = 1; k < A.ngroups; ++k) if (rg >= A.g_rg0[k]) gi = k;
+    const int p0 = A.g_p0[gi], nph = A.g_nph[gi], dcol = A.g_d[gi], sub = rg - A.g_rg0[gi];   // sub: 32-channel (full) / 64-channel (half) slice
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int nb32 = A.cin / 32, ngi = A.cin / 8, ngo = A.cout / 8;
+    const int f0 = tile * PG_FRAMES + wave * (16 * NT);           // first frame of the wave
+    const unsigned* wsrc = A.wp + (size_t)rg * nb32 * PG_RG_WORDS_PER_BLOCK;
+
+    f4 acc[8][NT];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int e = 0; e < NT; ++e) acc[mb][e] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // stage input block c (four K-steps = 64 KB) into buffer `buf`: 8 requests of 1 KB per wave
+    auto stage = [&](int c, int buf) {
+        const unsigned* src = wsrc + (size_t)c * PG_RG_WORDS_PER_BLOCK;
+#pragma unroll
+        for (int i = 0; i < PG_RG_WORDS_PER_BLOCK / 256 / PG_WAVES; ++i) {
+            const int piece = wave * (PG_RG_WORDS_PER_BLOCK / 256 / PG_WAVES) + i;
+            pg_dma16(src + (size_t)(piece * 64 + lane) * 4, lds_base + buf * (PG_RG_WORDS_PER_BLOCK * 4) + piece * 1024);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(A.x + (size_t)b * 2 * ngi * A.xs * 4), 0, 2 * ngi * A.xs * 16, 0x00020000);
+    const int lo_plane = ngi * A.xs * 16;
+    // input words of block c: frames f + d - (TP - 1) .. f + d + NT - 1 of the lane's first frame f
+    wn_u4 Rh[NR], Rl[NR];
+    auto loadB = [&](int c) {
+        const int vo = (4 * c + kg) * A.xs * 16 + (DC_XOFF + f0 + NT * n + dcol - (TP - 1)) * 16;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            Rh[k] = __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + k * 16, 0, 0));
+            Rl[k] = __builtin_bit_cast(wn_u4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + k * 16, lo_plane, 0));
+        }
+    };
+
+    stage(0, 0);
+    loadB(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nb32; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nb32) stage(c + 1, buf ^ 1);                               // (that buffer's readers passed the barrier below)
+#pragma unroll
+        for (int m = 0; m < TP; ++m) {
+            const wn_u4* Al = reinterpret_cast<const wn_u4*>(lds + buf * (PG_RG_WORDS_PER_BLOCK * 4)) + m * (PG_KS_WORDS / 4) + lane;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const wn_u4 ah = Al[mb * 128], al = Al[mb * 128 + 64];
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    const wn_u4 bh = Rh[e + TP - 1 - m], bl = Rl[e + TP - 1 - m];
+                    f4 cc = acc[mb][e];
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, bh), cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, ah), __builtin_bit_cast(wn_h8, bl), cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, al), __builtin_bit_cast(wn_h8, bh), cc, 0, 0, 0);
+                    acc[mb][e] = cc;
+                }
+            }
+        }
+        if (c + 1 < nb32) loadB(c + 1);                                        // (two waves per SIMD cover each other's wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's share of the next stage has landed
+        __syncthreads();
+    }
+    // ---- epilogue: bias, activation, fp16 split, G4 words of consecutive samples ----
+    // row block mb8 holds phase p0 + ph and 16-channel block cb16:  full: ph = mb8 >> 1, cb16 = 2 sub + (mb8 & 1);
+    // half: ph = mb8 >> 2, cb16 = 4 sub + (mb8 & 3).  G4 group g = 4 (cb16 >> 1) + kg takes blocks cb16 = 2 s', 2 s' + 1.
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(A.y + (size_t)b * 2 * ngo * A.ys * 4), 0, (int)(2 * ngo * A.ys * 16), 0x00020000);
+    const int lo_out = (int)(ngo * A.ys * 16);
+    float amax = 0.f;
+    const bool half = nph == 2;
+    const int cb_first = half ? 4 * sub : 2 * sub;
+    float bs[4][4];                                                            // [cb16 - cb_first][row] (full: two blocks)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) bs[k][rr] = (half || k < 2) ? A.bias[16 * (cb_first + k) + 4 * kg + rr] : 0.f;
+    // The words leave through an 8 KB LDS patch per wave (the fragment stages are free now), transposed so that FOUR
+    // CONSECUTIVE LANES hold the four words of one frame: a store instruction then writes 16 runs of 64 contiguous bytes
+    // (half groups: 32 runs of 32) instead of 64 scattered 16-byte pieces -- measured 39 us of a 134 us launch for the
+    // scattered form (profiles/r05_upsampler_variants.txt).
+    char* patch = lds + wave * 8192;
+    const int fr = f0 + NT * (lane >> 2);                  // frame of this lane in the store pass (+ e)
+    const int w2r = lane & 3;                              // ... and its word
+    const int phr = half ? (w2r & 1) : w2r, sgr = half ? (w2r >> 1) : 0;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            // word w2 of this frame: full -- phase w2 of the one G4 group; half -- phase w2 & 1 of G4 group w2 >> 1
+            wn_u4 hw, lw;
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                const int blk = slot >> 1, r0 = (slot & 1) * 2;
+                // (compile-time register indices: both variants are evaluated and selected)
+                const float a0 = half ? acc[(4 * (w2 & 1) + 2 * (w2 >> 1) + blk) & 7][e][r0] : acc[(2 * w2 + blk) & 7][e][r0];
+                const float a1 = half ? acc[(4 * (w2 & 1) + 2 * (w2 >> 1) + blk) & 7][e][r0 + 1] : acc[(2 * w2 + blk) & 7][e][r0 + 1];
+                const float b0 = half ? bs[2 * (w2 >> 1) + blk][r0] : bs[blk][r0];
+                const float b1 = half ? bs[2 * (w2 >> 1) + blk][r0 + 1] : bs[blk][r0 + 1];
+                const float v0 = apply_act(fmaf(a0, A.inv_scale, b0), A.act);
+                const float v1 = apply_act(fmaf(a1, A.inv_scale, b1), A.act);
+                unsigned a, c2;
+                wn_split_pair_t(v0, v1, a, c2, amax);
+                hw[slot] = a;
+                lw[slot] = c2;
+            }
+            *reinterpret_cast<wn_u4*>(patch + ((kg * 16 + n) * 4 + w2) * 16) = hw;
+            *reinterpret_cast<wn_u4*>(patch + 4096 + ((kg * 16 + n) * 4 + w2) * 16) = lw;
+        }
+        const int f = fr + e;
+        const int64_t tcol = A.yoff + (int64_t)A.S * f + p0 + phr;
+#pragma unroll
+        for (int kr = 0; kr < 4; ++kr) {
+            const int g = 4 * ((cb_first >> 1) + sgr) + kr;
+            const int vo = f < A.L ? (int)(((int64_t)g * A.ys + tcol) * 16) : (int)0x80000000;
+            const wn_u4 hw = *reinterpret_cast<const wn_u4*>(patch + (kr * 64 + lane) * 16);
+            const wn_u4 lw = *reinterpret_cast<const wn_u4*>(patch + 4096 + (kr * 64 + lane) * 16);
+            buf_st4(hw, ry, vo, 0);
+            buf_st4(lw, ry, vo, lo_out);
+        }
+    }
+    wn_range_flag(amax, A.status);
+}
+
 // channel-major [B][C][T] (row stride cs) -> reference layout [B][T][C]
 __global__ void cm_to_tm_kernel(const float* __restrict__ in, float* __restrict__ out,
                                 int C, int64_t T, int64_t cs) {
@@ -627,10 +821,63 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
                                 return sc * W[((size_t)(lp.S * tap + r) * lp.cout + 16 * mb + i16) * cin + ci];
                             });
             }
+            // phase-group pack (deconv_pg_kernel): [row group][input block c][tap m][row block mb8][plane][lane][4].
+            // Phase p uses kernel offset r = (p + pL) % S and input frame f + d - m, d = (p + pL) / S.  The phases of one d
+            // are cut into groups of four (full: 4 phases x 32 channels per row group) and a remainder of two (half:
+            // 2 phases x 64 channels per row group), so every row group has one d and 8 row blocks.
+            if (lp.w_off_h && !c.use_resize_conv && lp.taps == 4 && cin % 32 == 0 && lp.cout % 64 == 0) {
+                std::vector<int> gp0, gnph;
+                bool ok = true;
+                for (int p = 0; p < lp.S;) {
+                    const int d = (p + lp.pL) / lp.S;
+                    int q = p;
+                    while (q < lp.S && (q + lp.pL) / lp.S == d) ++q;          // phases [p, q) share d
+                    if ((q - p) & 1) { ok = false; break; }
+                    for (; q - p >= 4; p += 4) { gp0.push_back(p); gnph.push_back(4); }
+                    if (q - p == 2) { gp0.push_back(p); gnph.push_back(2); p += 2; }
+                }
+                if (ok && (int)gp0.size() <= 8) {
+                    const int nb32 = cin / 32;
+                    const float sc = 1.0f / lp.inv_scale_h;
+                    lp.pg_n = (int)gp0.size();
+                    int nrg = 0;
+                    for (int g = 0; g < lp.pg_n; ++g) {
+                        lp.pg_p0[g] = gp0[g]; lp.pg_nph[g] = gnph[g]; lp.pg_d[g] = (gp0[g] + lp.pL) / lp.S; lp.pg_rg0[g] = nrg;
+                        nrg += gnph[g] == 4 ? lp.cout / 32 : lp.cout / 64;
+                    }
+                    lp.pg_nrg = nrg;
+                    blob.resize(align_up(blob.size(), 64));
+                    lp.w_off_pg = blob.size();
+                    blob.resize(blob.size() + (size_t)nrg * nb32 * 4 * 4096);
+                    unsigned* PG = reinterpret_cast<unsigned*>(blob.data() + lp.w_off_pg);
+                    for (int g = 0; g < lp.pg_n; ++g) {
+                        const int nsub = gnph[g] == 4 ? lp.cout / 32 : lp.cout / 64;
+                        for (int sub = 0; sub < nsub; ++sub)
+                            for (int cb = 0; cb < nb32; ++cb)
+                                for (int m = 0; m < 4; ++m)
+                                    for (int mb8 = 0; mb8 < 8; ++mb8) {
+                                        const int ph = gnph[g] == 4 ? mb8 >> 1 : mb8 >> 2;
+                                        const int cb16 = gnph[g] == 4 ? 2 * sub + (mb8 & 1) : 4 * sub + (mb8 & 3);
+                                        const int r = (gp0[g] + ph + lp.pL) % lp.S;
+                                        pack_afrag(PG + (((((size_t)(lp.pg_rg0[g] + sub)) * nb32 + cb) * 4 + m) * 8 + mb8) * 512,
+                                                   [&](int e, int kg, int i16) {
+                                                       const int ci = 32 * cb + 16 * (e >> 2) + 4 * kg + (e & 3);
+                                                       return sc * W[((size_t)(lp.S * m + r) * lp.cout + 16 * cb16 + i16) * cin + ci];
+                                                   });
+                                    }
+                    }
+                }
+            }
             sp.layers.push_back(lp);
             cin = lp.cout;
         }
     }
+    return WN_OK;
+}
+
+int wn_deconv_set_attrs(wn_handle* h) {
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_pg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PG_LDS_BYTES));
     return WN_OK;
 }
 
@@ -702,6 +949,27 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
         const bool next_g4 = h_gemm && !last && (lp.cout % 32 == 0);
         // zero pads of an intermediate output: the G4 interleave writes them itself, the other forms get a memset
         if (!last && !next_g4) WN_HIP(h, hipMemsetAsync(y, 0, (size_t)B * lp.cout * ys * sizeof(float), st));
+        // (h->dc_no_pg: WN_DC_NO_PG=1 at wn_create keeps the phase-major GEMM + interleave of rounds 1-4: A/B runs, cross-form test)
+        if (h_gemm && in_g4 && last && split_out && lp.w_off_pg && !h->dc_no_pg) {
+            PgArgs A{};
+            A.x = reinterpret_cast<const unsigned*>(x);
+            A.cin = lp.cin; A.xs = xs; A.L = L;
+            A.wp = reinterpret_cast<const unsigned*>(h->d_blob + lp.w_off_pg);
+            A.bias = h->d_blob + lp.b_off;
+            A.inv_scale = lp.inv_scale_h;
+            A.y = reinterpret_cast<unsigned*>(y);
+            A.cout = lp.cout; A.S = lp.S; A.act = c.upsample_act;
+            A.ys = ys; A.yoff = yoff; A.status = status;
+            A.ngroups = lp.pg_n; A.nrg = lp.pg_nrg;
+            for (int g = 0; g < lp.pg_n; ++g) {
+                A.g_p0[g] = lp.pg_p0[g]; A.g_nph[g] = lp.pg_nph[g]; A.g_d[g] = lp.pg_d[g]; A.g_rg0[g] = lp.pg_rg0[g];
+            }
+            A.ntiles = (L + PG_FRAMES - 1) / PG_FRAMES;
+            hipLaunchKernelGGL(deconv_pg_kernel, dim3(lp.pg_nrg * A.ntiles, B), dim3(PG_WAVES * 64), PG_LDS_BYTES, st, A);
+            in_g4 = false;
+            x = y; xs = (int)ys; next = y + (size_t)B * lp.cout * ys; L = Lout;
+            continue;
+        }
         if (h_gemm) {
             dim3 g(Qp / DC_QW, lp.S, B * (lp.cout / 64));
             const unsigned* xin = reinterpret_cast<const unsigned*>(x);

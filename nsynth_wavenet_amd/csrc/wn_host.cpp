@@ -179,6 +179,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             h->hoist_limit_bytes = std::min(h->hoist_limit_bytes, (double)free_b * 0.5);
     }
     {   // A/B switches of the layer-group kernel, read ONCE (a handle may be shared by concurrent callers)
+        const char* np = getenv("WN_DC_NO_PG");
+        h->dc_no_pg = np && atoi(np) != 0;
         const char* ng = getenv("WN_NO_GROUPS");
         const char* fg = getenv("WN_GROUPS");
         if (ng && atoi(ng) != 0) h->groups_env = -1;
@@ -296,6 +298,8 @@ extern "C" int wn_finalize(wn_handle* h) {
         rc = wn_iaf_set_attrs(h);
         if (rc) return rc;
     }
+    rc = wn_deconv_set_attrs(h);
+    if (rc) return rc;
     // host copies are no longer needed
     for (auto& kv : h->vars) std::vector<float>().swap(kv.second.data);
     h->finalized = true;

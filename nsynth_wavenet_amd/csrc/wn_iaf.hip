@@ -699,6 +699,20 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     const bool f16x3 = prec == WN_PREC_F16X3;
 
     const bool use_groups = f16x3 && wn_iaf_use_groups(h, B, L.T, L.form);
+    // measurement aid (wn_profile_parts_begin): an event where a part of the call begins.  Parts: 0 prologue / epilogue
+    // (pads, noise, final), 1 upsampler, 2 conditioning GEMM, 3 residual stack (start convs, layers, heads)
+    int part_now = -2;
+    auto part = [&](int tag) -> int {
+        if (!h->parts_on || tag == part_now) return WN_OK;
+        hipEvent_t ev;
+        WN_HIP(h, hipEventCreate(&ev));
+        h->part_events.push_back(ev);
+        h->part_tags.push_back(tag);
+        WN_HIP(h, hipEventRecord(ev, st));
+        part_now = tag;
+        return WN_OK;
+    };
+    if (int rc = part(0)) return rc;
     // zero left pads
     {
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
@@ -726,8 +740,10 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     const unsigned* cond_tab = blob_u(h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
     if (c.share_deconv) {
+        if (int rc = part(1)) return rc;
         int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
         if (rc) return rc;
+        if (hoist) if (int rc2 = part(2)) return rc2;
         if (hoist)
             wn_iaf_c_cond(enc, h->d_blob, cond_tab, blob_u(use_groups ? h->order_all_off : h->order_id_off),
                           use_groups ? h->n_nat_all : h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T,
@@ -740,14 +756,17 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     for (int k = 0; k < c.n_flows; ++k) {
         const IafFlowPack& fp = h->flows[k];
         if (!c.share_deconv) {
+            if (int rc = part(1)) return rc;
             int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
             if (rc) return rc;
+            if (hoist) if (int rc2 = part(2)) return rc2;
             if (hoist)
                 wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base,
                               use_groups ? blob_u(h->order_flow_off) + fp.rb_base : blob_u(h->order_id_off),
                               use_groups ? h->n_nat_flow[k] : (int)fp.layers.size() + 1, Cc, L.c_bstride, L.TE, L.c0,
                               (int)fp.layers.size() + 1, B, L.T, h->num_cu, st);
         }
+        if (int rc = part(3)) return rc;
         // row blocks of this flow inside C (all flows when the deconv stack is shared)
         const float* Cf = Cc + (c.share_deconv ? (size_t)fp.rb_base * rb_floats : 0);
         if (use_groups) {
@@ -866,6 +885,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
                                encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
                                tiles_per_row, ntiles);
     }
+    if (int rc = part(0)) return rc;
     {
         const int64_t nn = (int64_t)B * L.T;
         const int Q = c.use_mu_law ? 256 : 65536;
@@ -874,6 +894,8 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         if (rand_out && rand_out != x0)
             WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
+    if (int rc = part(-1)) return rc;
+    if (h->parts_on) ++h->part_calls;
     WN_HIP(h, hipGetLastError());
     return WN_OK;
 }
@@ -1013,6 +1035,36 @@ extern "C" int wn_profile_begin(wn_handle* h) {
     h->prof_events.clear();
     h->prof_launches = 0;
     h->prof_on = true;
+    return WN_OK;
+}
+
+extern "C" int wn_profile_parts_begin(wn_handle* h) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_begin: null handle");
+    for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);
+    h->part_events.clear();
+    h->part_tags.clear();
+    h->part_calls = 0;
+    h->parts_on = true;
+    return WN_OK;
+}
+
+extern "C" int wn_profile_parts_end(wn_handle* h, double* part_ms, int64_t* calls) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_end: null handle");
+    h->parts_on = false;
+    double ms[WN_PROFILE_PARTS] = {0.0};
+    for (size_t i = 0; i + 1 < h->part_events.size(); ++i) {
+        const int tag = h->part_tags[i];
+        if (tag < 0 || tag >= WN_PROFILE_PARTS) continue;          // -1: between two calls
+        float f = 0.f;
+        WN_HIP(h, hipEventSynchronize(h->part_events[i + 1]));
+        WN_HIP(h, hipEventElapsedTime(&f, h->part_events[i], h->part_events[i + 1]));
+        ms[tag] += f;
+    }
+    for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);
+    h->part_events.clear();
+    h->part_tags.clear();
+    if (part_ms) for (int i = 0; i < WN_PROFILE_PARTS; ++i) part_ms[i] = ms[i];
+    if (calls) *calls = h->part_calls;
     return WN_OK;
 }
 

@@ -34,155 +34,173 @@
 
 namespace {
 
-constexpr int CK_NC = 128;                       // columns of one conditioning-GEMM task
+constexpr int CK_NC = 128;                       // columns of one conditioning-GEMM tile
 constexpr int CK_THREADS = 512;                  // 8 waves: two per SIMD hide each other's load / store latency
-constexpr int CK_NBS = 17;                       // 16-byte words per column block in the LDS tile (16 + 1 pad: the gather
-constexpr int CK_RS = 8 * CK_NBS;                //   of a decimated tile writes at stride 17, conflict-free like the reads)
-constexpr int CK_LDS_BYTES = 2 * 32 * CK_RS * 16;   // enc tile: [plane][group][column block][column] x 16 B
+constexpr int CK_RS = CK_NC;                     // 16-byte words per (plane, group) row of the LDS tile: rows 2 KB apart, the
+                                                 //   conflict-free kind of ds_read_b128 (scripts/ubench/lds_b128_stride.hip)
+constexpr int CK_LDS_BYTES = 2 * 32 * CK_RS * 16;   // enc tile: [plane][group][column block][column] x 16 B = 128 KB
 constexpr int CK_DEC = 32;                       // decimation of the row blocks that feed a "dec" layer group (wn_iaf_g.hip)
 
+// LDS-DMA of 64 x 16 B (lane i's bytes land at lds_byte_addr + 16 i), issued from asm: through the builtin the compiler
+// would put s_waitcnt vmcnt(0) in front of every later LDS access (wn_iaf_g.hip has the same helper and the reason)
+__device__ inline void ck_dma16(const unsigned* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
 // ---------------- conditioning GEMM: C[rb] = Wcond[rb] (64 x 256) . enc (256 x T) ----------------
-// One task = (batch row, 128-column tile, chunk of row blocks).  The enc tile is staged once in
-// LDS as ready-made B operands; each wave then owns whole row blocks: its A fragments come
-// straight from L2 in fragment order (1 KB per wave load), every fragment is used against
-// the 8 column blocks of the tile, every B operand read from LDS feeds 12 MFMAs.
-// Row blocks come in two kinds (order[0 .. n_nat) natural, order[n_nat .. R) decimated; a chunk never mixes them):
+// The enc tile of 128 columns sits in LDS as ready-made B operands; each wave owns whole row blocks: its A fragments
+// come straight from L2 in fragment order (1 KB per wave load), every fragment is used against the 8 column blocks of
+// the tile, every B operand read from LDS feeds 12 MFMAs.
+// Row blocks come in two kinds (order[0 .. n_nat) natural, order[n_nat .. R) decimated):
 //   natural   -- tile j = columns [128 j, 128 j + 128), column block nb = 16 consecutive samples, C block 8 j + nb;
 //   decimated -- the layer (or head) runs in a decimated layer group of wn_iaf_g.hip, which walks the residue classes
 //                t = r (mod 32): tile j = (k = j / 4, rg = j % 4) = residues 8 rg .. 8 rg + 7 x decimated columns
 //                16 k .. 16 k + 15, column block nb = residue 8 rg + nb, C block (8 rg + nb) * (T / 512) + k.  The
-//                tile is GATHERED from enc in 128-byte runs (8 residues x 16 B) and holds the same 128 samples' worth
-//                of operands, so the MFMA loop is identical.
+//                tile is GATHERED from enc (64-byte runs: four residues x 16 B per decimated column) and holds the same
+//                128 samples' worth of operands, so the MFMA loop is identical.
+// Work list (round 5).  A UNIT is one sub-round: the eight waves of a workgroup take one row block each against one
+// staged tile.  Units are ordered (tile, kind, sub-round) -- natural tile j and decimated tile j cover the same 512-sample
+// neighbourhood of enc -- and every workgroup takes ONE CONTIGUOUS RANGE of them, equal to within one unit (4 800 units on
+// 256 workgroups at one utterance: 18 or 19 each, where rounds of whole (tile, 32-row-block chunk) tasks cost the fullest
+// workgroup 20).  A range crosses tile boundaries; the tile is restaged whenever (tile, kind) changes, by LDS-DMA: 16
+// requests of 1 KB per wave issued back to back and ONE wait, instead of four batches of global loads -> registers -> LDS
+// stores (the staging bubble was ~10 of the ~78 us of a four-sub-round task).
 __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
     const unsigned* __restrict__ enc, const unsigned* __restrict__ wblob, const unsigned* __restrict__ rb_off,
     const unsigned* __restrict__ order, int n_nat, float* __restrict__ C, int64_t c_bstride, int64_t TE, int c0, int R,
-    int CH, int nch_nat, int nchunks, int tiles_per_row, int ntiles, int64_t NCB) {
+    int sr_nat, int sr_dec, int tiles_per_row, int ntiles, int64_t NCB) {
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     constexpr int NW = CK_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, q = lane >> 4;
-    wn_u4* Bt = reinterpret_cast<wn_u4*>(ldsw);
-    const int TE16 = (int)TE * 16;
+    const wn_u4* Bt = reinterpret_cast<const wn_u4*>(ldsw);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsw);
     const int NBD = (int)(NCB / CK_DEC);          // decimated column blocks per residue
+    const int upt = sr_nat + sr_dec;              // units per tile
+    const int64_t U = (int64_t)ntiles * upt;
 
-    int first, end, step, t_lo;
+    // contiguous unit range of this workgroup; every XCD takes one contiguous eighth (its L2 then holds one stretch of enc)
+    int64_t u_lo, u_hi;
     if ((gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7, per = (ntiles + 7) >> 3;
-        t_lo = xcd * per;
-        const int t_hi = min(ntiles, t_lo + per);
-        first = blockIdx.x >> 3;
-        step = gridDim.x >> 3;
-        end = t_hi > t_lo ? (t_hi - t_lo) * nchunks : 0;
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, nx = gridDim.x >> 3;
+        const int64_t x_lo = U * xcd / 8, x_hi = U * (xcd + 1) / 8;
+        u_lo = x_lo + (x_hi - x_lo) * i / nx;
+        u_hi = x_lo + (x_hi - x_lo) * (i + 1) / nx;
     } else {
-        t_lo = 0;
-        first = blockIdx.x;
-        step = gridDim.x;
-        end = ntiles * nchunks;
+        u_lo = U * blockIdx.x / gridDim.x;
+        u_hi = U * (blockIdx.x + 1) / gridDim.x;
     }
-    for (int task = first; task < end; task += step) {
-        const int tile = t_lo + task / nchunks, chunk = task % nchunks;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7ffffff0, 0x00020000);
+    int staged_tile = -1, staged_kind = -1;
+    // row block of this wave in unit u (clamped to the last one of its kind where a sub-round is short: `have` false)
+    auto unit_rb = [&](int64_t u, bool& have) -> int {
+        const int tile = (int)(u / upt), su = (int)(u - (int64_t)tile * upt);
+        const bool dec = su >= sr_nat;
+        const int p_end = dec ? R : n_nat;
+        const int pos = (dec ? n_nat : 0) + (dec ? su - sr_nat : su) * NW + wave;
+        have = pos < p_end;
+        return (int)order[have ? pos : p_end - 1];
+    };
+    wn_u4 a[2][4][2];
+    if (u_lo < u_hi) {      // first A fragments of the wave's first row block: in flight while the tile is staged
+        bool hv;
+        const int ao = (int)rb_off[unit_rb(u_lo, hv)] * 4;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            a[0][mb][0] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 0) * 1024);
+            a[0][mb][1] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 1) * 1024);
+        }
+    }
+    for (int64_t u = u_lo; u < u_hi; ++u) {
+        const int tile = (int)(u / upt), su = (int)(u - (int64_t)tile * upt);
+        const bool dec = su >= sr_nat;
         const int b = tile / tiles_per_row;
         const int j = tile - b * tiles_per_row;
-        const bool dec = chunk >= nch_nat;
-        const int p_lo = dec ? n_nat + (chunk - nch_nat) * CH : chunk * CH;
-        const int p_end = min(dec ? R : n_nat, p_lo + CH);
-        int pos = p_lo + wave;
-        // first A fragments of this wave's first row block: in flight while the tile is staged
-        wn_u4 a[2][4][2];
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7ffffff0, 0x00020000);
-        {
-            const int ao = (int)rb_off[order[min(pos, p_end - 1)]] * 4;
+        bool have, have_next;
+        const int rb = unit_rb(u, have);
+        const int ao = (int)rb_off[rb] * 4;
+        // the NEXT unit's first fragments are requested during this unit's last K-step (a short sub-round's idle wave: now)
+        const int an = (int)rb_off[unit_rb(u + 1 < u_hi ? u + 1 : u, have_next)] * 4;
+        if (tile != staged_tile || (int)dec != staged_kind) {
+            // ---- stage the enc tile: 64 rows (plane, group) x 8 column blocks x 16 columns x 16 B, one DMA request per
+            // half row; word position p = 64 half + lane of a row is column 16 nb + n of the tile (nb = p >> 4, n = p & 15)
+            const unsigned* eb = enc + (size_t)b * IAF_CD * TE;      // (32-bit words: [2 planes][32 groups][TE][4])
+            __syncthreads();                      // the previous unit's operand reads are done
+#pragma unroll
+            for (int k = 0; k < 64 * 2 / NW; ++k) {
+                const int req = wave * (64 * 2 / NW) + k, row = req >> 1, p = (req & 1) * 64 + lane;
+                int src_col = dec ? CK_DEC * (16 * (j >> 2) + (p & 15)) + 8 * (j & 3) + (p >> 4) : CK_NC * j + p;
+                src_col = min(c0 + src_col, (int)TE - 1);      // (columns past the utterance: their results are dropped below)
+                ck_dma16(eb + ((size_t)row * TE + src_col) * 4, lds_base + row * (CK_RS * 16) + (req & 1) * 1024);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also the eight fragment loads above)
+            __syncthreads();
+            staged_tile = tile;
+            staged_kind = (int)dec;
+        }
+        if (!have) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                a[0][mb][0] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 0) * 1024);
-                a[0][mb][1] = buf_ld4(rw, lane * 16, ao + (mb * 2 + 1) * 1024);
+                a[0][mb][0] = buf_ld4(rw, lane * 16, an + (mb * 2 + 0) * 1024);
+                a[0][mb][1] = buf_ld4(rw, lane * 16, an + (mb * 2 + 1) * 1024);
             }
+            continue;
         }
-        // ---- stage the enc tile: 64 rows (plane, group) x 8 column blocks x 16 columns x 16 B ----
-        {
-            const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(enc + (size_t)b * IAF_CD * TE), 0, IAF_CD * (int)TE * 4, 0x00020000);
-            constexpr int RP = CK_THREADS / CK_NC;          // rows per pass
-            const int col = threadIdx.x & (CK_NC - 1), rp = threadIdx.x / CK_NC;
-            int src_col, dst;
-            if (dec) {       // thread = (decimated column col / 8, residue col % 8): 8 lanes fetch one 128-byte run
-                src_col = CK_DEC * (16 * (j >> 2) + (col >> 3)) + 8 * (j & 3) + (col & 7);
-                dst = (col & 7) * CK_NBS + (col >> 3);
-            } else {
-                src_col = CK_NC * j + col;
-                dst = (col >> 4) * CK_NBS + (col & 15);
-            }
-            const int vo = (c0 + src_col) * 16 + rp * TE16;
-            __syncthreads();                      // previous task's operand reads are done
+        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(C + (size_t)b * c_bstride + ((size_t)rb * NCB) * 1024), 0, (int)NCB * 4096, 0x00020000);
+        f4 acc[4][8];
 #pragma unroll
-            for (int c4 = 0; c4 < 64 / RP / 4; ++c4) {
-                wn_u4 tmp[4];
+        for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    tmp[p] = buf_ld4<WN_ENC_STAGE_AUX>(re, vo, (RP * (4 * c4 + p)) * TE16);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) Bt[(RP * (4 * c4 + p) + rp) * CK_RS + dst] = tmp[p];
-            }
-            __syncthreads();
-        }
-        for (; pos < p_end; pos += NW) {
-            const int rb = (int)order[pos];
-            const int ao = (int)rb_off[rb] * 4, an = (int)rb_off[order[min(pos + NW, p_end - 1)]] * 4;
-            const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(C + (size_t)b * c_bstride + ((size_t)rb * NCB) * 1024), 0, (int)NCB * 4096, 0x00020000);
-            f4 acc[4][8];
+            for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = (f4){0.f, 0.f, 0.f, 0.f};
+        // B operands one (K-step, column block) ahead of the MFMAs that use them
+        wn_u4 bb[2][2];
+        bb[0][0] = Bt[q * CK_RS + n];
+        bb[0][1] = Bt[(32 + q) * CK_RS + n];
+        __builtin_amdgcn_sched_barrier(0);     // not part of the first K-step's (2 LDS reads, 12 MFMAs) groups
+        auto store_nb = [&](int nb) {
+            // column blocks past the end of the row fall outside the descriptor and are dropped
+            const int cb = dec ? (8 * (j & 3) + nb) * NBD + (j >> 2) : (CK_NC / 16) * j + nb;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
+                buf_st4<WN_C_ST_AUX>(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16, (cb * 4 + mb) * 1024);   // (guarded store: wn_mfma_h.h)
+        };
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = (f4){0.f, 0.f, 0.f, 0.f};
-            // B operands one (K-step, column block) ahead of the MFMAs that use them
-            wn_u4 bb[2][2];
-            bb[0][0] = Bt[q * CK_RS + n];
-            bb[0][1] = Bt[(32 + q) * CK_RS + n];
-            __builtin_amdgcn_sched_barrier(0);     // not part of the first K-step's (2 LDS reads, 12 MFMAs) groups
-            auto store_nb = [&](int nb) {
-                // column blocks past the end of the row fall outside the descriptor and are dropped
-                const int cb = dec ? (8 * (j & 3) + nb) * NBD + (j >> 2) : (CK_NC / 16) * j + nb;
+        for (int ks = 0; ks < 8; ++ks) {
+            // next K-step's fragments (the next unit's first ones at the end)
+            const int an1 = ks + 1 < 8 ? ao + (ks + 1) * 8 * 1024 : an;
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, acc[mb][nb]), rcb, lane * 16,
-                                                           (cb * 4 + mb) * 1024, WN_C_ST_AUX);
-            };
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                // next K-step's fragments (the next row block's first ones at the end)
-                const int an1 = ks + 1 < 8 ? ao + (ks + 1) * 8 * 1024 : an;
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
-                    a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
-                }
-#pragma unroll
-                for (int nb = 0; nb < 8; ++nb) {
-                    const int cur = nb & 1;
-                    if (ks * 8 + nb + 1 < 64) {
-                        const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
-                        bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_RS + CK_NBS * nb1 + n];
-                        bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_RS + CK_NBS * nb1 + n];
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
-                    // results of a column block leave while the next one is being computed
-                    if (ks == 7 && nb >= 1) store_nb(nb - 1);
-                    // the eight fragment loads of the next K-step go out FIRST (left alone the scheduler sinks them
-                    // to the end of the K-step and the next one starts by waiting a full L2 round trip for them)
-                    if (nb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int mb = 0; mb < 4; ++mb) {
+                a[(ks + 1) & 1][mb][0] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 0) * 1024);
+                a[(ks + 1) & 1][mb][1] = buf_ld4(rw, lane * 16, an1 + (mb * 2 + 1) * 1024);
             }
-            store_nb(7);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                const int cur = nb & 1;
+                if (ks * 8 + nb + 1 < 64) {
+                    const int ks1 = (ks * 8 + nb + 1) >> 3, nb1 = (nb + 1) & 7;
+                    bb[cur ^ 1][0] = Bt[(4 * ks1 + q) * CK_RS + 16 * nb1 + n];
+                    bb[cur ^ 1][1] = Bt[(32 + 4 * ks1 + q) * CK_RS + 16 * nb1 + n];
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
+                // results of a column block leave while the next one is being computed
+                if (ks == 7 && nb >= 1) store_nb(nb - 1);
+                // the eight fragment loads of the next K-step go out FIRST (left alone the scheduler sinks them
+                // to the end of the K-step and the next one starts by waiting a full L2 round trip for them)
+                if (nb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        store_nb(7);
     }
 }
 
@@ -880,27 +898,13 @@ void wn_iaf_c_cond(const float* enc, const float* wblob, const unsigned* rb_off,
     const int tiles_per_row = (int)((T + CK_NC - 1) / CK_NC), ntiles = B * tiles_per_row;
     constexpr int NW = CK_THREADS / 64;
     const int n_dec = R - n_nat;
-    // split each kind's row blocks into chunks of CH so that the persistent grid ends its last round full
-    int best_ch = (std::max(n_nat, n_dec) + NW - 1) / NW * NW;
-    double best_cost = 1e30;
-    for (int ch = NW; ch <= (std::max(n_nat, n_dec) + NW - 1) / NW * NW; ch += NW) {
-        const int nch = (n_nat + ch - 1) / ch + (n_dec + ch - 1) / ch;
-        // work of one tile: staging per chunk + one sub-round per NW row blocks of each chunk
-        double per_tile = 0.5 * nch;
-        for (int k = 0; k < 2; ++k)
-            for (int left = k ? n_dec : n_nat; left > 0; left -= ch) per_tile += (std::min(left, ch) + NW - 1) / NW;
-        const int64_t rounds = ((int64_t)ntiles * nch + num_cu - 1) / num_cu;
-        const double cost = (double)rounds * per_tile / nch;
-        if (cost < best_cost) { best_cost = cost; best_ch = ch; }
-    }
-    if (const char* e = getenv("WN_COND_CH")) best_ch = std::max(NW, atoi(e) / NW * NW);
-    const int ch = best_ch;
-    const int nch_nat = (n_nat + ch - 1) / ch, nchunks = nch_nat + (n_dec + ch - 1) / ch;
-    const int64_t ntasks = (int64_t)ntiles * nchunks;
-    const int grid = (int)std::min<int64_t>(ntasks, num_cu);
+    const int sr_nat = (n_nat + NW - 1) / NW, sr_dec = (n_dec + NW - 1) / NW;   // sub-rounds of eight row blocks per tile
+    const int64_t units = (int64_t)ntiles * (sr_nat + sr_dec);
+    int grid = (int)std::min<int64_t>(units, num_cu);
+    if (grid >= 8) grid = grid / 8 * 8;                                          // XCD-aware ranges: a multiple of 8
     hipLaunchKernelGGL(iaf_cond_h_kernel, dim3(grid), dim3(CK_THREADS), CK_LDS_BYTES, st,
                        reinterpret_cast<const unsigned*>(enc), reinterpret_cast<const unsigned*>(wblob), rb_off, order,
-                       n_nat, C, c_bstride, TE, c0, R, ch, nch_nat, nchunks, tiles_per_row, ntiles, T / 16);
+                       n_nat, C, c_bstride, TE, c0, R, sr_nat, sr_dec, tiles_per_row, ntiles, T / 16);
 }
 
 // workgroups per CU of the hoisted layer / head kernels (57 KB of LDS; the 128-column variant

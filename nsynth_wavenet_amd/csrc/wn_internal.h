@@ -30,6 +30,11 @@ struct DeconvLayerPack {
     size_t w_off_h;                    // split-fp16 A fragments (0 = not available for this shape)
     float inv_scale_h;
     size_t b_off;                      // bias [cout]
+    // phase-group pack of deconv_pg_kernel (0 = not available): per group of four output phases, A fragments of
+    // (4 phases x 32 channels) row groups over (input block, tap); see wn_deconv.hip
+    size_t w_off_pg = 0;
+    int pg_n = 0, pg_nrg = 0;                                         // phase groups, row groups (512 KB of fragments each)
+    int pg_p0[8] = {0}, pg_nph[8] = {0}, pg_d[8] = {0}, pg_rg0[8] = {0};   // first phase, phases (4 | 2), input column offset, first row group
 };
 
 struct DeconvStackPack {
@@ -145,6 +150,7 @@ struct wn_handle {
     int num_cu = 256;
     // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
     int cond_env_mode = 0;                    // WN_COND_AUTO or the form named by the environment
+    bool dc_no_pg = false;                    // WN_DC_NO_PG=1 at wn_create: upsampler without the phase-group kernel (wn_deconv.hip)
     int groups_env = 0;                       // WN_GROUPS=1 -> +1 (always), WN_NO_GROUPS=1 -> -1 (never), else 0 (policy)
     double hoist_limit_bytes = 96e9;          // a third of the device memory
     mutable std::string err;
@@ -155,6 +161,12 @@ struct wn_handle {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // begin/end pairs
     int64_t prof_launches = 0;
+    // second mode (wn_profile_parts_begin/end): one event at every PART boundary of a generate call instead of the
+    // brackets around the residual-stack launches; part_tags[i] = part that starts at part_events[i] (-1: call ends)
+    bool parts_on = false;
+    std::vector<hipEvent_t> part_events;
+    std::vector<int> part_tags;
+    int64_t part_calls = 0;
 };
 
 // ---- error helpers ----
@@ -217,6 +229,7 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F,
 int wn_pack_iaf_h(wn_handle* h, std::vector<float>& blob);
 // ---- generic-width student (wn_iaf_x.hip) ----
 int wn_pack_iaf_x(wn_handle* h, std::vector<float>& blob);
+int wn_deconv_set_attrs(wn_handle* h);
 int wn_iaf_x_set_attrs(wn_handle* h);
 void wn_iaf_x_start(const wn_handle* h, const IafFlowX& fx, const float* x, float* l, int64_t T, int XR, int64_t RS, int B,
                     hipStream_t st);

@@ -255,6 +255,18 @@ class Engine(object):
         self._check(self.lib.wn_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    PROFILE_PARTS = ('prologue_epilogue', 'upsampler', 'cond_gemm', 'residual_stack')
+
+    def profile_parts_begin(self):
+        self._check(self.lib.wn_profile_parts_begin(self._h))
+
+    def profile_parts_end(self):
+        """-> ({part: summed ms}, calls): HIP events at the part boundaries of every iaf_generate since parts_begin."""
+        ms = (ctypes.c_double * len(self.PROFILE_PARTS))()
+        n = ctypes.c_int64(0)
+        self._check(self.lib.wn_profile_parts_end(self._h, ms, ctypes.byref(n)))
+        return {k: ms[i] for i, k in enumerate(self.PROFILE_PARTS)}, n.value
+
     # ---- AR path ----
     def ar_n_rand(self):
         return int(self.lib.wn_ar_n_rand(self._h))

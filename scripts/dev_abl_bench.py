@@ -36,5 +36,16 @@ for i in range(a.steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms, n = eng.profile_end()
-print('{:24s} B={} {:8.4f} ms/call   residual-stack launches: {:7.2f} us avg over {}'.format(
-    os.path.basename(a.tag), a.batch, dt / a.steps * 1e3, ms * 1e3 / max(n, 1), n), flush=True)
+parts = ''
+if hasattr(eng, 'profile_parts_begin') and hasattr(eng.lib, 'wn_profile_parts_begin'):
+    eng.profile_parts_begin()
+    for i in range(10):
+        eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
+    pms, pn = eng.profile_parts_end()
+    parts = '   parts us/call: ' + ' '.join('{} {:.1f}'.format(k[:5], v * 1e3 / max(pn, 1)) for k, v in pms.items())
+# a digest of one call on fixed inputs: equal digests = bit-identical results (arithmetic-preserving variants)
+import hashlib
+x = eng.iaf_generate(mel, None, seed=4242, want=('x',), check_range=False)['x']
+dig = hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:10]
+print('{:24s} B={} {:8.4f} ms/call   residual-stack launches: {:7.2f} us avg over {}{}   x digest {} finite {}'.format(
+    os.path.basename(a.tag), a.batch, dt / a.steps * 1e3, ms * 1e3 / max(n, 1), n, parts, dig, bool(torch.isfinite(x).all())), flush=True)

@@ -403,6 +403,41 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
         eng.close()
 
 
+def test_phase_group_upsampler_matches_the_phase_major_form(monkeypatch):
+    """The last upsampler layer of the split-fp16 path runs as ONE launch (deconv_pg_kernel: four consecutive output phases
+    x 32 channels per wave tile, G4 words written from the GEMM epilogue; 2 + 2 phases where a group of four would
+    straddle two input frames) instead of phase-major GEMM + interleave (masked.py:235-291, wavenet.py:46-73).  Same
+    products, another summation order over the taps: held against the old form (WN_DC_NO_PG=1 at engine creation) at
+    fp32-rounding level and against the float64 oracle, on one tile, ragged last tiles (L not a multiple of 640 frames),
+    several utterances, the centre-crop shapes, the fused and hoisted forms, tanh activation and private stacks."""
+    from oracle import wavenet_np as O
+    rs = np.random.RandomState(91)
+    for extra, shapes in (({}, ((1, 8), (2, 35), (1, 70), (3, 129), (1, 384))),
+                          ({'upsample_act': 'tanh', 'use_share_deconv': False, 'num_iaf_layers': [10, 10]}, ((2, 21), (1, 66)))):
+        cfgd = dict(load_json('parallel_wavenet.json'), **extra)
+        hp = O.HP(cfgd)
+        w = O.synth_weights(hp, 'student', seed=777, init='tf')
+        monkeypatch.delenv('WN_DC_NO_PG', raising=False)
+        new = {p: _engine(cfgd, w, p) for p in ('f16x3', 'f16x3-fused')}
+        monkeypatch.setenv('WN_DC_NO_PG', '1')
+        old = _engine(cfgd, w, 'f16x3')
+        monkeypatch.delenv('WN_DC_NO_PG', raising=False)
+        for B, F in shapes:
+            T = O.iaf_length(F, hp)
+            mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
+            noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
+            xo = _np(old.iaf_generate(mel, noise, want=('x',))['x'])
+            for p, e in new.items():
+                xn = _np(e.iaf_generate(mel, noise, want=('x',))['x'])
+                assert np.isfinite(xn).all(), (extra, B, F, p)
+                assert np.abs(xn - xo).max() <= 4e-6 * max(1.0, np.abs(xo).max()), (extra, B, F, p)
+            if F <= 70:
+                ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)['x']
+                assert np.abs(xn - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (extra, B, F)
+        for e in list(new.values()) + [old]:
+            e.close()
+
+
 @pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused'])
 def test_repeated_calls_are_bit_identical_at_full_size(precision):
     """Six calls on the same inputs at the headline size (one utterance, 384 frames, 76 800 samples: 4 800 blocks x 60
