@@ -353,6 +353,90 @@ def part_rooflines(eng, hp, B, F, T, part_us, pm):
     return out
 
 
+class HwmonSampler:
+    """Package power (W) and shader clock (MHz) of one GPU from its hwmon node, sampled on a thread beside a run.  The part
+    runs this workload AT ITS POWER CAP (1 400 W): what the kernels can reach is set by energy per sample, and the clock the
+    firmware grants is an output of the measurement, not a constant (profiles/r05_power_per_part.txt)."""
+
+    def __init__(self, index, period_s=0.005):
+        import glob
+        import threading
+        self.period = period_s
+        self.p, self.f = [], []
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = '{:04x}:{:02x}:{:02x}.0'.format(pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob('/sys/bus/pci/devices/{}/hwmon/hwmon*'.format(bdf))
+            self.dir = hw[0] if hw else None
+        except Exception:                    # measurement garnish only
+            self.dir = None
+        self._on = False
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return int(f.read().strip())
+
+    def _run(self):
+        while self._on:
+            try:
+                self.p.append(self._read('power1_input') * 1e-6)
+                self.f.append(self._read('freq1_input') * 1e-6)
+            except (OSError, ValueError):
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dir:
+            self._on = True
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._on:
+            self._on = False
+            self._th.join()
+
+    def summary(self):
+        if not self.p:
+            return None
+        cap = None
+        try:
+            cap = self._read('power1_cap') * 1e-6
+        except (OSError, ValueError):
+            pass
+        return {'avg_W': float(np.mean(self.p)), 'max_W': float(np.max(self.p)), 'cap_W': cap, 'avg_sclk_MHz': float(np.mean(self.f)),
+                'samples': len(self.p)}
+
+
+def measure_power(eng, mel, rank, local, seconds=1.5):
+    """Sustained run of the same step with the package power and the shader clock sampled beside it: J per step, and how
+    much of the power cap the workload takes.  Behind the timed region; asynchronous calls like the timed ones."""
+    def burst(n):
+        for i in range(n):
+            eng.iaf_generate(mel, None, seed=9000 + 1000 * rank + i, want=('wav',), check_range=False)
+        torch.cuda.synchronize()
+    t_end = time.perf_counter() + 0.5
+    while time.perf_counter() < t_end:       # reach the steady operating point first
+        burst(20)
+    n = 0
+    with HwmonSampler(local) as hs:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            burst(20)
+            n += 20
+        dt = time.perf_counter() - t0
+    sm = hs.summary()
+    if not sm:
+        return None
+    sm.update({'ms_per_step_sustained': dt / n * 1e3, 'J_per_step': sm['avg_W'] * dt / n, 'steps': n,
+               'frac_of_power_cap': sm['avg_W'] / sm['cap_W'] if sm['cap_W'] else None,
+               'note': 'hwmon power1_input / freq1_input of this GPU sampled every 5 ms beside a sustained run of the step; '
+                       'at the cap the step time is energy per step over (cap - static power): profiles/r05_power_per_part.txt'})
+    return sm
+
+
 def measure_parts(eng, mel, rank, calls=10):
     """Per-part microseconds of a generate call, measured in THIS process: HIP events at the part boundaries of `calls`
     calls behind the timed region (each event costs the stream a few microseconds: the parts sum to slightly more than
@@ -499,7 +583,7 @@ def main():
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
-                    help='skip the second roofline block (8 utterances per GPU) and the PCIe-inclusive timing')
+                    help='skip everything behind the timed region: part timing, power sampling, the AR / teacher figures, the PCIe-inclusive call, the 8-utterance and fp32 blocks')
     ap.add_argument('--layer-events-every', type=int, default=20,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
@@ -601,7 +685,7 @@ def main():
             },
             'roofline': roof,
         }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         # Where the call's time goes, measured in THIS process (HIP events at the part boundaries of ten more calls) --
         # not replayed from a profile -- and the roofline blocks of the two parts that are not the dominant kernel.
         part_us, n_parts = measure_parts(eng, mel, rank)
@@ -610,6 +694,11 @@ def main():
                                          '(wn_profile_parts_*), this process, behind the timed region')
         pm_all = pmc_replay(B, F, eng.precision, eng.iaf_cond_hoisted(B, F), rec['roofline'].get('kernel', '').split(' ')[0])
         rec.update(part_rooflines(eng, hp, B, F, T, part_us, pm_all))
+        pw = measure_power(eng, mel, rank, local)
+        eng.check_range()
+        if pw:
+            pw['uJ_per_sample'] = pw['J_per_step'] / (B * T) * 1e6
+            rec['power'] = pw
     if world == 1 and not args.no_extras:
         # (0) the other BASELINE.json configs that fit one GPU, driver-timed in the same line: configs[3] (wavenet_mol.json
         #     autoregressive fastgen, one utterance) and its batched form, and the teacher's full-sequence forward

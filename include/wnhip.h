@@ -270,6 +270,13 @@ int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn,
                    const float* forced_wav, float* out_params,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Fastgen.cond_vars / fastgen.calculate_cond_vars (wavenet/wavenet.py:353-377, wavenet/fastgen.py:91-115): the 1x1
+ * conditioning projections of every layer and of the output stage, in bulk over time, biases included.
+ * enc [B,Tn,deconv_width] (wn_deconv's output); out: num_layers tensors [B,Tn,gate_width] ('mel_cond_1' ..
+ * 'mel_cond_<num_layers>') back to back, then 'mel_cond_out1' [B,Tn,skip_width] -- wn_ar_cond_vars_floats(h,B,Tn) floats. */
+size_t wn_ar_cond_vars_floats(const wn_handle* h, int B, int Tn);
+int wn_ar_cond_vars(wn_handle* h, const float* enc, int B, int Tn, float* out, void* stream);
+
 /* wn_ar_generate replays the step from a hipGraph (16 steps per graph) when the caller's stream can be
  * captured (any stream but the legacy null stream); enable = 0 makes it issue plain launches instead
  * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  A failed capture falls back to
@@ -294,9 +301,10 @@ int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, int B, 
 int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
 /* 1 when wn_iaf_generate(B, F) runs the residual layers in layer groups (up to five layers per launch with the residual
- * stream in LDS: one natural and one decimated group per ten-layer dilation cycle) -- the default of the hoisted form for
- * small calls (up to four utterances of 4.8 s per GPU), where launch count is what the layers cost; 0 when every layer
- * (or layer pair) is a launch of its own. */
+ * stream in LDS: one natural and one decimated group per ten-layer dilation cycle) -- the default of the hoisted form
+ * whenever the flows split into alternating natural / decimated groups and the length is a multiple of 512 samples (every
+ * shipped configuration), except for five to seven 4.8 s utterances per call, where the per-layer launches measured 1 %
+ * ahead; 0 when every layer (or layer pair) is a launch of its own. */
 int wn_iaf_layer_groups(const wn_handle* h, int B, int F);
 
 /* Launch structure of the hoisted form for this handle: mode 1 = layer groups at every call size they support, -1 = never
@@ -329,6 +337,13 @@ int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches);
 #define WN_PROFILE_PARTS 4
 int wn_profile_parts_begin(wn_handle* h);
 int wn_profile_parts_end(wn_handle* h, double* part_ms, int64_t* calls);
+
+/* POWER measurements only: restrict the following wn_iaf_generate calls of the split-fp16 / fp32 student paths to the parts
+ * whose bits are set in mask (bit k = part k above; 15 = everything, the state of a new handle) -- e.g. a loop of
+ * conditioning GEMMs alone, so that the package power and the clock the part holds under that kernel can be read beside
+ * it (scripts/dev_power.sh).  The skipped parts leave their buffers as the last full call wrote them; results of a
+ * restricted call are meaningless.  Not thread-safe; returns WN_EINVAL for a mask outside 1..15. */
+int wn_profile_parts_only(wn_handle* h, int mask);
 
 /* Last error message of this handle (or of wn_create when h == NULL). */
 const char* wn_last_error(const wn_handle* h);

@@ -21,8 +21,8 @@ SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_ia
            'wn_ar_length', 'wn_workspace_bytes', 'wn_deconv', 'wn_iaf_generate', 'wn_iaf_generate_form',
            'wn_iaf_workspace_bytes_form', 'wn_iaf_range_status', 'wn_iaf_range_reset',
            'wn_iaf_range_status_since_reset', 'wn_clip_quant',
-           'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph',
-           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
+           'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph', 'wn_ar_cond_vars', 'wn_ar_cond_vars_floats',
+           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_profile_parts_only', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
 
 
 class WnConfig(ctypes.Structure):
@@ -85,6 +85,9 @@ def load():
     lib.wn_ar_step.argtypes = [vp, vp, i32, vp, vp, vp, u64, vp, vp, vp]
     lib.wn_ar_generate.argtypes = [vp, vp, i32, i32, vp, u64, vp, vp, vp, vp, vp, sz, vp]
     lib.wn_ar_set_graph.argtypes = [vp, i32]
+    lib.wn_ar_cond_vars_floats.argtypes = [vp, i32, i32]
+    lib.wn_ar_cond_vars_floats.restype = sz
+    lib.wn_ar_cond_vars.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.wn_iaf_cond_hoisted.argtypes = [vp, i32, i32]
     lib.wn_iaf_layer_groups.argtypes = [vp, i32, i32]
     lib.wn_iaf_set_groups.argtypes = [vp, i32]
@@ -95,6 +98,7 @@ def load():
     lib.wn_profile_pause.argtypes = [vp, c.c_int]
     lib.wn_profile_end.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]
     lib.wn_profile_parts_begin.argtypes = [vp]
+    lib.wn_profile_parts_only.argtypes = [vp, i32]
     lib.wn_profile_parts_end.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]
     lib.wn_mel_frames.argtypes = [i64]
     lib.wn_mel_frames.restype = i64

@@ -974,6 +974,8 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
             const auto& bd = var("dilated_conv_" + s + "/biases");
             const auto& bc = var("mel_cond_" + s + "/biases");
             for (int o = 0; o < G; ++o) blob.push_back(bd[o] + bc[o]);
+            lp.bc_off = begin();
+            blob.insert(blob.end(), bc.begin(), bc.end());
         }
         lp.wrs_off = begin();
         blob.resize(blob.size() + (size_t)(W + S) * (G / 2));
@@ -1015,6 +1017,8 @@ int wn_pack_ar(wn_handle* h, std::vector<float>& blob) {
         const auto& b1 = var("out1/biases");
         const auto& b2 = var("mel_cond_out1/biases");
         for (int o = 0; o < S; ++o) blob.push_back(b1[o] + b2[o]);
+        P.bco1_off = begin();
+        blob.insert(blob.end(), b2.begin(), b2.end());
         P.wo2_off = begin();
         blob.resize(blob.size() + (size_t)OW * S);
         pack_T(wn_get_kernel(h, "out2", "W", false), S, OW, blob.data() + P.wo2_off, S, 0);
@@ -1180,6 +1184,84 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     }
     for (int i = 0; i < multi; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_multi, st));
     for (int i = 0; i < rest; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_one, st));
+    return WN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fastgen.cond_vars (wavenet/wavenet.py:353-377; fastgen.calculate_cond_vars, fastgen.py:91-115): every layer's 1x1
+// conditioning projection mel_cond_i(encoding) -- and mel_cond_out1 -- evaluated in bulk over time, biases included, in
+// the reference's [B, T, channels] layout.  The reference builds it "for data visualization"; the sampling loop
+// (Fastgen.sample) keeps evaluating the projections per step, and so does the step here: the conditioning columns are 256
+// of the 2 048 inputs of a gate row, the step is a chain of launch-latency-bound kernels at every batch size, and a timing
+// ablation without them (profiles/r05_ar_step_variants.txt) bounds what hoisting could buy.
+// out[col][g] = bias[g] + sum_c W[g][koff + c] * enc[col][c]: a plain LDS-tiled fp32 GEMM, 64 x 64 outputs per workgroup.
+namespace {
+constexpr int CV_T = 64, CV_K = 16;
+__global__ __launch_bounds__(256) void ar_cond_vars_kernel(const float* __restrict__ Wm, int ldw, int koff, const float* __restrict__ bias,
+                                                           const float* __restrict__ enc, int Cd, int rows, int64_t cols, float* __restrict__ out) {
+    __shared__ float Ws[CV_K][CV_T + 1], Es[CV_K][CV_T + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;            // 4 x 4 outputs per thread: rows 4 tx.., columns 4 ty..
+    const int g0 = blockIdx.x * CV_T;
+    const int64_t c0 = (int64_t)blockIdx.y * CV_T;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < Cd; k0 += CV_K) {
+        for (int i = threadIdx.x; i < CV_T * CV_K; i += 256) {
+            const int r = i / CV_K, k = i - r * CV_K;
+            Ws[k][r] = (g0 + r < rows) ? Wm[(size_t)(g0 + r) * ldw + koff + k0 + k] : 0.f;
+            Es[k][r] = (c0 + r < cols) ? enc[(size_t)(c0 + r) * Cd + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CV_K; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = Ws[k][4 * tx + i]; b[i] = Es[k][4 * ty + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][i] = fmaf(a[i], b[j], acc[j][i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t col = c0 + 4 * ty + j;
+        if (col >= cols) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = g0 + 4 * tx + i;
+            if (g < rows) out[(size_t)col * rows + g] = acc[j][i] + bias[g];
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t wn_ar_cond_vars_floats(const wn_handle* h, int B, int Tn) {
+    if (!h || h->cfg.kind != WN_KIND_TEACHER || B < 1 || Tn < 1) return 0;
+    return (size_t)B * Tn * ((size_t)h->cfg.num_layers * h->cfg.gate_width + h->cfg.skip_width);
+}
+
+extern "C" int wn_ar_cond_vars(wn_handle* h, const float* enc, int B, int Tn, float* out, void* stream) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_ar_cond_vars: null handle");
+    if (!h->finalized) return wn_fail(h, WN_ESTATE, "wn_ar_cond_vars: call wn_finalize first");
+    if (h->cfg.kind != WN_KIND_TEACHER) return wn_fail(h, WN_EINVAL, "wn_ar_cond_vars: handle is not a Wavenet teacher");
+    if (B < 1 || Tn < 1 || !enc || !out) return wn_fail(h, WN_EINVAL, "wn_ar_cond_vars: bad argument");
+    const wn_config& c = h->cfg;
+    const ArPack& P = h->ar;
+    const int G = c.gate_width, S = c.skip_width, Cd = c.deconv_width, W = c.width;
+    const int64_t cols = (int64_t)B * Tn;
+    if ((cols + CV_T - 1) / CV_T > 65535) return wn_fail(h, WN_EINVAL, "wn_ar_cond_vars: B * Tn = %lld exceeds 4 194 240 columns per call", (long long)cols);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 gy((unsigned)1, (unsigned)((cols + CV_T - 1) / CV_T));
+    float* dst = out;
+    for (const ArLayerPack& lp : P.layers) {                    // 'mel_cond_%d' % (i + 1): [B, Tn, gate_width]
+        hipLaunchKernelGGL(ar_cond_vars_kernel, dim3((G + CV_T - 1) / CV_T, gy.y), dim3(256), 0, st, h->d_blob + lp.wd_off,
+                           3 * W + Cd, 3 * W, h->d_blob + lp.bc_off, enc, Cd, G, cols, dst);
+        dst += (size_t)cols * G;
+    }
+    hipLaunchKernelGGL(ar_cond_vars_kernel, dim3((S + CV_T - 1) / CV_T, gy.y), dim3(256), 0, st, h->d_blob + P.wo1_off,   // 'mel_cond_out1'
+                       S + Cd, S, h->d_blob + P.bco1_off, enc, Cd, S, cols, dst);
+    WN_HIP(h, hipGetLastError());
     return WN_OK;
 }
 

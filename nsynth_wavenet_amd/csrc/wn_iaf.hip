@@ -739,12 +739,13 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     auto blob_u = [&](size_t off) { return reinterpret_cast<const unsigned*>(h->d_blob + off); };
     const unsigned* cond_tab = blob_u(h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
+    const int pmask = h->parts_mask;                     // (0xf except under wn_profile_parts_only)
     if (c.share_deconv) {
         if (int rc = part(1)) return rc;
-        int rc = wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
+        int rc = (pmask & 2) ? wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec) : WN_OK;
         if (rc) return rc;
         if (hoist) if (int rc2 = part(2)) return rc2;
-        if (hoist)
+        if (hoist && (pmask & 4))
             wn_iaf_c_cond(enc, h->d_blob, cond_tab, blob_u(use_groups ? h->order_all_off : h->order_id_off),
                           use_groups ? h->n_nat_all : h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T,
                           h->num_cu, st);
@@ -757,16 +758,17 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         const IafFlowPack& fp = h->flows[k];
         if (!c.share_deconv) {
             if (int rc = part(1)) return rc;
-            int rc = wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec);
+            int rc = (pmask & 2) ? wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec) : WN_OK;
             if (rc) return rc;
             if (hoist) if (int rc2 = part(2)) return rc2;
-            if (hoist)
+            if (hoist && (pmask & 4))
                 wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base,
                               use_groups ? blob_u(h->order_flow_off) + fp.rb_base : blob_u(h->order_id_off),
                               use_groups ? h->n_nat_flow[k] : (int)fp.layers.size() + 1, Cc, L.c_bstride, L.TE, L.c0,
                               (int)fp.layers.size() + 1, B, L.T, h->num_cu, st);
         }
         if (int rc = part(3)) return rc;
+        if (!(pmask & 8)) continue;
         // row blocks of this flow inside C (all flows when the deconv stack is shared)
         const float* Cf = Cc + (c.share_deconv ? (size_t)fp.rb_base * rb_floats : 0);
         if (use_groups) {
@@ -959,16 +961,20 @@ bool wn_iaf_hoisted(const wn_handle* h, int B, int64_t T) {
 
 // The layer-group kernel (wn_iaf_g.hip) runs the hoisted form whenever every flow has a group plan and the decimated
 // view exists (T a multiple of 32 * 16); lA then keeps the natural layout and lB the DL layout for the whole call.
-// Where it pays: the group launch is bound by the SIMD issue of a CU (its halo costs 17 % more matrix and VALU work than the
-// per-layer kernels, which in turn pay a launch per layer or layer pair).  End of round 4 (profiles/r04_batch_sweep.txt,
-// configs[1] utterances on one box, ms per call groups | per-layer launches): 1.254 | 1.494 at one, 2.465 | 2.695 at two,
-// 3.651 | 3.811 at three, 4.808 | 4.893 at four, 9.448 | 9.482 at eight (a tie).
-// Default: while a natural group has at most four segments per CU.  WN_GROUPS=1 forces it on at any batch size,
-// WN_NO_GROUPS=1 off (A/B measurements, cross-form tests).
+// Where it pays (round 5, profiles/r05_batch_sweep.txt; configs[1] utterances on one box, ms per call groups | per-layer
+// launches): 1.19 | 1.43 at one utterance, 4.71 | 4.74 at four, 6.99 | 6.92 at six, 9.30 | 9.29 at eight, 13.91 | 14.27 at twelve,
+// 18.35 | 18.78 at sixteen.  From two utterances on BOTH forms run at the package power cap, so what decides
+// is energy per sample: the group form moves the residual stream through the fabric twice per ten layers instead of eight
+// times, the per-layer form has no halo recompute; the groups are 2.3-2.5 % ahead from twelve utterances and within +-1 % of
+// the per-layer form below (second sweep, same file: the per-layer form 0.6-1.5 % ahead at five to seven utterances, the
+// groups 0.5 % ahead at eight, 3.5 % at ten).  Default: groups, except between 4.5 and 7 segments per CU.  wn_iaf_set_groups
+// (or WN_GROUPS=1 / WN_NO_GROUPS=1 at wn_create) forces either form (A/B measurements, cross-form tests).
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
     if (form != WN_COND_HOISTED || !h->groups_ok || T % 512 != 0) return false;
     if (h->groups_env) return h->groups_env > 0;                // wn_iaf_set_groups; WN_NO_GROUPS / WN_GROUPS set its initial value in wn_create
-    return (int64_t)B * ((T / 16 + 19) / 20) <= 4 * (int64_t)h->num_cu;
+    // five to seven utterances' worth of segments: the per-layer launches are 0.6-1.5 % ahead there (r05_batch_sweep.txt)
+    const int64_t segs = (int64_t)B * ((T / 16 + 19) / 20);
+    return segs <= 4 * (int64_t)h->num_cu + h->num_cu / 2 || segs > 7 * (int64_t)h->num_cu;
 }
 
 extern "C" int wn_iaf_set_groups(wn_handle* h, int mode) {
@@ -1045,6 +1051,13 @@ extern "C" int wn_profile_parts_begin(wn_handle* h) {
     h->part_tags.clear();
     h->part_calls = 0;
     h->parts_on = true;
+    return WN_OK;
+}
+
+extern "C" int wn_profile_parts_only(wn_handle* h, int mask) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_only: null handle");
+    if (mask < 1 || mask > 0xf) return wn_fail(h, WN_EINVAL, "wn_profile_parts_only: mask must be in 1..15, got %d", mask);
+    h->parts_mask = mask;
     return WN_OK;
 }
 

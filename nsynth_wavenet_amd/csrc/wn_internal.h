@@ -84,6 +84,7 @@ struct IafFlowX {
 struct ArLayerPack {
     size_t wd_off;    // [gate][3*width + deconv_width]   (taps t-2d, t-d, t, cond)
     size_t bd_off;    // [gate]  (dilated bias + cond bias)
+    size_t bc_off = 0;   // [gate]  cond bias alone (wn_ar_cond_vars)
     size_t wrs_off;   // [width + skip][gate/2]            (res rows then skip rows)
     size_t brs_off;   // [width + skip]
     size_t wd_b_off, wrs_b_off;   // the same matrices in MFMA A-fragment order (batched step)
@@ -100,6 +101,7 @@ struct ArPack {
     size_t wss_off, bss_off;   // skip_start [skip][width], [skip]
     std::vector<ArLayerPack> layers;
     size_t wo1_off, bo1_off;   // [skip][skip + deconv_width], [skip] (out1 | mel_cond_out1)
+    size_t bco1_off = 0;       // [skip] mel_cond_out1 bias alone (wn_ar_cond_vars)
     size_t wo2_off, bo2_off;   // [out_width][skip], [out_width]
     size_t wss_b_off, wo1_b_off, wo2_b_off;   // A-fragment order copies
     size_t ring_floats;        // per batch element
@@ -163,6 +165,7 @@ struct wn_handle {
     int64_t prof_launches = 0;
     // second mode (wn_profile_parts_begin/end): one event at every PART boundary of a generate call instead of the
     // brackets around the residual-stack launches; part_tags[i] = part that starts at part_events[i] (-1: call ends)
+    int parts_mask = 0xf;                     // wn_profile_parts_only: parts a generate call runs (measurement only: bit = part tag)
     bool parts_on = false;
     std::vector<hipEvent_t> part_events;
     std::vector<int> part_tags;

@@ -260,6 +260,10 @@ class Engine(object):
     def profile_parts_begin(self):
         self._check(self.lib.wn_profile_parts_begin(self._h))
 
+    def profile_parts_only(self, mask):
+        """Power measurements only: run just the parts whose bits are set (bit k = PROFILE_PARTS[k]; 15 = everything)."""
+        self._check(self.lib.wn_profile_parts_only(self._h, int(mask)))
+
     def profile_parts_end(self):
         """-> ({part: summed ms}, calls): HIP events at the part boundaries of every iaf_generate since parts_begin."""
         ms = (ctypes.c_double * len(self.PROFILE_PARTS))()
@@ -304,6 +308,27 @@ class Engine(object):
             self._check(self.lib.wn_ar_step(self._h, _ptr(state), B, _ptr(wav_in), _ptr(enc_t), _ptr(rnd),
                                             ctypes.c_uint64(int(seed)), _ptr(sample), _ptr(outp), self._stream()))
         return (sample, outp) if want_out else sample
+
+    def ar_cond_vars(self, enc):
+        """Fastgen.cond_vars (wavenet.py:353-377): enc [B,Tn,deconv_width] -> {'mel_cond_1': [B,Tn,gate_width], ...,
+        'mel_cond_<num_layers>': ..., 'mel_cond_out1': [B,Tn,skip_width]}, every layer's conditioning projection (bias
+        included) in bulk over time.  The tensors are views of one device buffer."""
+        enc = self._dev(enc)
+        if enc.dim() != 3 or int(enc.shape[2]) != int(self.hp.deconv_width):
+            raise ValueError('ar_cond_vars: enc must be [batch, steps, {}], got {}'.format(self.hp.deconv_width, tuple(enc.shape)))
+        B, Tn = int(enc.shape[0]), int(enc.shape[1])
+        G, S, NL = cfg.teacher_gate_width(self.hp), int(self.hp.skip_width), int(self.hp.num_layers)
+        n = int(self.lib.wn_ar_cond_vars_floats(self._h, B, Tn))
+        if n != B * Tn * (NL * G + S):
+            raise ValueError('ar_cond_vars: needs a teacher engine and B, Tn >= 1')
+        buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_ar_cond_vars(self._h, _ptr(enc), B, Tn, _ptr(buf), self._stream()))
+        out = {}
+        for i in range(NL):
+            out['mel_cond_%d' % (i + 1)] = buf[i * B * Tn * G:(i + 1) * B * Tn * G].view(B, Tn, G)
+        out['mel_cond_out1'] = buf[NL * B * Tn * G:].view(B, Tn, S)
+        return out
 
     def ar_generate(self, enc, rnd=None, seed=0, forced_wav=None, want_out=False, use_graph=False):
         """fastgen.synthesis loop.  enc [B,Tn,deconv_width], rnd [Tn,B,ar_n_rand()] or None (drawn on the

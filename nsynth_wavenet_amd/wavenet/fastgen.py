@@ -66,6 +66,12 @@ def encode(hparams, wav_data, checkpoint_path):
     return encode_mel(hparams, mel_val, checkpoint_path)
 
 
+def calculate_cond_vars(hparams, encoding, checkpoint_path):
+    """fastgen.py:91-115: the per-layer conditioning projections of `encoding` [B, T, deconv_width] as numpy arrays."""
+    eng = _teacher_engine(hparams, checkpoint_path)
+    return {k: v.cpu().numpy() for k, v in eng.ar_cond_vars(np.asarray(encoding, np.float32)).items()}
+
+
 def generate(hparams, mel_encoding, checkpoint_path, rnd=None, seed=None):
     eng = _teacher_engine(hparams, checkpoint_path)
     if seed is None:

@@ -61,6 +61,11 @@ class Fastgen(_TeacherBase):
         self.state = self.engine.ar_new_state(self.batch_size)
         return self
 
+    def cond_vars(self, inputs):
+        """wavenet.py:353-377: {'mel_cond_1' .. 'mel_cond_<num_layers>', 'mel_cond_out1'} of inputs['encoding']
+        [B, T, deconv_width], each [B, T, gate_width] ([B, T, skip_width] for the last) -- one bulk evaluation on the device."""
+        return self.engine.ar_cond_vars(inputs['encoding'])
+
     def sample(self, inputs, rnd=None, seed=0, want_out=False):
         if self.state is None:
             self.init()

@@ -1,7 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_iaf.py -x -q -k "golden or phase_group or ragged or full_size" 2>&1 | tail -4
-for r in 1 2; do
-WN_DC_NO_PG=1 python scripts/dev_abl_bench.py --tag nopg --steps 50 2>&1 | tail -1 | tee -a gpurun_out/r5_ab_pg2.txt
-python scripts/dev_abl_bench.py --tag pg_coalesced --steps 50 2>&1 | tail -1 | tee -a gpurun_out/r5_ab_pg2.txt
+timeout 600 python -m pytest tests/test_gpu_ar.py -x -q 2>&1 | tail -3
+for r in 1 2 3; do
+  WN_AR_TAIL3=1 python bench_aux.py --workload ar --batch 1 --samples 1600 --steps 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ar B=1 three-launch tail', round(d['config']['us_per_sample_step'],2), 'us/step')"
+  python bench_aux.py --workload ar --batch 1 --samples 1600 --steps 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ar B=1 merged tail      ', round(d['config']['us_per_sample_step'],2), 'us/step')"
 done
-python scripts/dev_abl_bench.py --tag pg_coalesced_b8 --batch 8 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/r5_ab_pg2.txt
-WN_DC_NO_PG=1 python scripts/dev_abl_bench.py --tag nopg_b8 --batch 8 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/r5_ab_pg2.txt

@@ -260,6 +260,39 @@ def test_graph_replay_matches_plain_launches_and_inputs_are_checked(B):
     eng.close()
 
 
+def test_cond_vars_match_the_reference_definition():
+    """Fastgen.cond_vars (wavenet.py:353-377) / fastgen.calculate_cond_vars (fastgen.py:91-115): mel_cond_i(encoding) for every
+    layer and mel_cond_out1, biases included, [B, T, channels] -- against a float64 evaluation of the same 1x1 convolutions
+    on the variables (masked.conv1d with filter_length 1: x @ W[0, 0] + b), through the Python mirror, on a shipped
+    teacher and on one with a doubled gate and odd sizes (ragged 64 x 64 tiles)."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.wavenet.wavenet import Fastgen
+    rs = np.random.RandomState(5)
+    for patch, B, Tn in (({}, 2, 77), ({'double_gate_width': True, 'num_layers': 4, 'num_stages': 2, 'width': 64, 'skip_width': 64}, 3, 130)):
+        cfgd = dict(load_json('wavenet_mol.json'), **patch)
+        hp = O.HP(cfgd)
+        w = O.synth_weights(hp, 'teacher', seed=99, init='unit')
+        fg = Fastgen(cfgd, batch_size=B).load_weights(w)
+        enc = (rs.standard_normal([B, Tn, cfgd['deconv_width']]) * 0.5).astype(np.float32)
+        cv = fg.cond_vars({'encoding': enc})
+        names = ['mel_cond_%d' % (i + 1) for i in range(cfgd['num_layers'])] + ['mel_cond_out1']
+        assert sorted(cv.keys()) == sorted(names)
+        for nme in names:
+            Wk = np.asarray(w[nme + '/W'], np.float64)
+            ref = enc.astype(np.float64) @ Wk.reshape(Wk.shape[-2], Wk.shape[-1]) + np.asarray(w[nme + '/biases'], np.float64)
+            got = _np(cv[nme])
+            assert got.shape == ref.shape, (nme, got.shape, ref.shape)
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), nme
+        fg.engine.close()
+    with pytest.raises(ValueError):
+        from nsynth_wavenet_amd.engine import Engine
+        e = Engine(load_json('wavenet_mol.json'))
+        try:
+            e.ar_cond_vars(np.zeros([1, 4, 17], np.float32))
+        finally:
+            e.close()
+
+
 def test_teacher_configs_outside_the_kernel_limits_are_refused():
     """The AR step kernels hold one weight row in a register tile: 3*width + deconv_width <= 4096 (2048 on the tuned
     instantiation, the rest on the wide one), gate_width/2 <= 2048, 1 <= mol_mix <= 64 -- anything else must fail at

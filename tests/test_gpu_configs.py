@@ -81,7 +81,7 @@ def test_config0_student_on_the_fixture_shaped_utterance():
 @pytest.mark.parametrize('batch', [2, 3])
 def test_layer_groups_at_two_and_three_full_size_utterances(batch):
     """BASELINE configs[1] length (F = 384 -> T = 76 800) at the other batch sizes the launch policy gives to the
-    layer-group kernel (wn_iaf_use_groups: up to three 4.8 s utterances per GPU): the group form against the independent
+    layer-group kernel (the default form): the group form against the independent
     torch-CPU implementation on every sample of every utterance, the per-layer form on the same call, and row
     independence (utterance b of the batched call == the same utterance alone, bit for bit)."""
     import torch

@@ -387,7 +387,7 @@ def test_layer_groups_match_per_layer_launches(monkeypatch):
             T = O.iaf_length(F, hp)
             mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
             noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
-            eng.set_layer_groups(True)                    # at any batch size (the default keeps it to small calls)
+            eng.set_layer_groups(True)
             assert eng.iaf_layer_groups(B, F)             # ... so that the comparison cannot degenerate into a form against itself
             a = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
             a2 = {k: _np(v) for k, v in eng.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()}
@@ -560,6 +560,13 @@ def test_full_size_batch8_hoisted_conditioning():
     for row in (0, 5):
         one = _np(eng.iaf_generate(mel[row:row + 1], noise[row:row + 1], want=('x',))['x'])
         assert np.abs(one[0] - x[row]).max() <= 5e-6 * max(1.0, np.abs(one).max())
+    # the call takes the layer-group form by default (round 5: at every size); the per-layer / layer-pair launches -- the
+    # fallback of flows the group plan cannot cover -- on the same eight utterances
+    assert eng.iaf_layer_groups(B, F)
+    eng.set_layer_groups(False)
+    assert not eng.iaf_layer_groups(B, F)
+    xl = _np(eng.iaf_generate(mel, noise, want=('x',))['x']).astype(np.float64)
+    assert np.abs(xl - x).max() <= 5e-6 * max(1.0, np.abs(x).max())
     eng.close()
 
 
