@@ -44,6 +44,10 @@ PATH_BYTES_PER_SAMPLE = 98484
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+# What the matrix pipes SUSTAIN on this part with operands that look like data: a bare v_mfma_f32_16x16x32_f16 loop on all
+# 1 024 SIMDs settles at ~1.92 GHz / ~1 270 W (scripts/ubench/mfma_power.hip, profiles/r05_mfma_power_ubench.txt; zeros: 2.38 GHz).
+# Reported BESIDE the fractions of the nominal peak, never instead of them.
+SUSTAINED_F16_MFMA_TFLOPS = 1657.0
 BARRIER_KW = {}
 RED_DEV = None
 PROFILE_ROUND = 'r05'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
@@ -290,9 +294,12 @@ def three_fracs(alg_flop, moved_bytes, seconds, mfma_per_product=3, peak_tf=PEAK
     frac_mfma_exec  executed MFMA FLOP/s (x3 for the split-fp16 contraction: three fp16 MFMAs per product) over it,
     frac_hbm_moved  bytes the launch(es) must move in THIS design (not SURVEY 8(d)'s per-layer model) over 8 TB/s."""
     alg_tf = alg_flop / seconds / 1e12
-    return {'frac_mfma_alg': alg_tf / peak_tf, 'frac_mfma_exec': mfma_per_product * alg_tf / peak_tf,
-            'frac_hbm_moved': moved_bytes / seconds / 1e9 / PEAK_HBM_GBPS,
-            'algorithmic_TFLOPs': alg_tf, 'executed_TFLOPs': mfma_per_product * alg_tf, 'moved_GBps': moved_bytes / seconds / 1e9}
+    out = {'frac_mfma_alg': alg_tf / peak_tf, 'frac_mfma_exec': mfma_per_product * alg_tf / peak_tf,
+           'frac_hbm_moved': moved_bytes / seconds / 1e9 / PEAK_HBM_GBPS,
+           'algorithmic_TFLOPs': alg_tf, 'executed_TFLOPs': mfma_per_product * alg_tf, 'moved_GBps': moved_bytes / seconds / 1e9}
+    if peak_tf == PEAK_F16_MFMA_TFLOPS:
+        out['frac_mfma_exec_of_sustained'] = mfma_per_product * alg_tf / SUSTAINED_F16_MFMA_TFLOPS   # of the bare-MFMA-loop rate at the power-limited clock
+    return out
 
 
 def part_rooflines(eng, hp, B, F, T, part_us, pm):
@@ -688,17 +695,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # Where the call's time goes, measured in THIS process (HIP events at the part boundaries of ten more calls) --
         # not replayed from a profile -- and the roofline blocks of the two parts that are not the dominant kernel.
-        part_us, n_parts = measure_parts(eng, mel, rank)
-        eng.check_range()
-        rec['kernel_us_per_call'] = dict(part_us, calls=n_parts, source='HIP events at the part boundaries inside the library '
-                                         '(wn_profile_parts_*), this process, behind the timed region')
-        pm_all = pmc_replay(B, F, eng.precision, eng.iaf_cond_hoisted(B, F), rec['roofline'].get('kernel', '').split(' ')[0])
-        rec.update(part_rooflines(eng, hp, B, F, T, part_us, pm_all))
+        # (the sustained run first: the parts are then timed at the operating point the firmware settles on, not in the
+        # clock transient behind a 25-step run from an idle GPU)
         pw = measure_power(eng, mel, rank, local)
         eng.check_range()
         if pw:
             pw['uJ_per_sample'] = pw['J_per_step'] / (B * T) * 1e6
             rec['power'] = pw
+        part_us, n_parts = measure_parts(eng, mel, rank, calls=20)
+        eng.check_range()
+        rec['kernel_us_per_call'] = dict(part_us, calls=n_parts, sum_us=sum(part_us.values()),
+                                         source='HIP events at the part boundaries inside the library (wn_profile_parts_*), this '
+                                                'process, behind the timed region and the sustained run; every event costs the '
+                                                'stream a few microseconds: the parts sum to slightly more than a call')
+        pm_all = pmc_replay(B, F, eng.precision, eng.iaf_cond_hoisted(B, F), rec['roofline'].get('kernel', '').split(' ')[0])
+        rec.update(part_rooflines(eng, hp, B, F, T, part_us, pm_all))
     if world == 1 and not args.no_extras:
         # (0) the other BASELINE.json configs that fit one GPU, driver-timed in the same line: configs[3] (wavenet_mol.json
         #     autoregressive fastgen, one utterance) and its batched form, and the teacher's full-sequence forward

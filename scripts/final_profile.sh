@@ -22,8 +22,14 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin8 -o fin8 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --batch-per-gpu 8 > $R/gpurun_out/fin8.log 2>&1
 cd $R; for f in gpurun_out/bench_*.json; do python -c "
 import json; d=json.load(open('$f')); r=d['roofline']; print('$f', round(d['value']/1e6,3),'Ms/s', round(d['ms_per_step'],3),'ms', r['bound'], round(r['achieved'],1), round(r['frac'],3), r.get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done
+# package power / shader clock / energy per part, and the bare matrix pipe's sustained rate
+python scripts/dev_power.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/power_per_part.txt
+python scripts/dev_power.py --batch 8 --seconds 2 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/power_per_part.txt
+HW=$(grep -m1 "^hwmon" gpurun_out/power_per_part.txt | awk '{print $2}')
+[ -x scripts/ubench/mfma_power ] && scripts/ubench/mfma_power $HW 3 | tee gpurun_out/mfma_power.txt
+python scripts/dev_ramp.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ramp.txt
 # batch sweep of the two launch structures (policy of wn_iaf_use_groups): ms per call
-for b in 1 2 3 4 8; do
+for b in 1 2 4 6 8 12 16; do
   WN_GROUPS=1 python scripts/dev_abl_bench.py --tag groups --batch $b --steps 40 2>/dev/null | tail -1
   WN_NO_GROUPS=1 python scripts/dev_abl_bench.py --tag per-layer --batch $b --steps 40 2>/dev/null | tail -1
 done | tee gpurun_out/batch_sweep.txt

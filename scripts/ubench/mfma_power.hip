@@ -1,0 +1,83 @@
+// Micro-benchmark: what fp16 MFMA rate does the part SUSTAIN, and at which package power and shader clock?  A pure
+// v_mfma_f32_16x16x32_f16 loop (no memory, no LDS, no VALU) on all 1 024 SIMDs for a few seconds per operand pattern, with
+// the GPU's hwmon nodes (power1_input, freq1_input) sampled from the host beside it.  Patterns: all-zero operands, one
+// constant, random halves rotating through 8 register pairs (an operand changes every instruction, as in the kernels).
+// The kernels of this repository run at the 1 400 W package cap; this is the same question for the bare
+// matrix pipe: the nominal 2.5 PFLOP/s is the rate AT 2.4 GHz, and the clock is what the power budget leaves.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o mfma_power mfma_power.hip     run: ./mfma_power <hwmon dir> [seconds]
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int NACC, int NOP>
+__global__ __launch_bounds__(256) void k(float* out, const float* in, int iters) {
+    f4 acc[NACC];
+    h8 a[NOP], b[NOP];
+    for (int o = 0; o < NOP; ++o)
+        for (int i = 0; i < 8; ++i) {
+            a[o][i] = (_Float16)in[(threadIdx.x + 17 * o + i) & 1023];
+            b[o][i] = (_Float16)in[(threadIdx.x + 29 * o + 8 + i) & 1023];
+        }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + i) % NOP], b[(u + 3 * i) % NOP], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+static long read_long(const std::string& p) {
+    FILE* f = fopen(p.c_str(), "r");
+    if (!f) return -1;
+    long v = -1;
+    if (fscanf(f, "%ld", &v) != 1) v = -1;
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char** argv) {
+    const std::string hw = argc > 1 ? argv[1] : "";
+    const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
+    float *out, *in;
+    hipMalloc(&out, 4096 * 256 * 4);
+    hipMalloc(&in, 1024 * 4);
+    std::vector<float> h(1024);
+    printf("cap %.0f W\n", read_long(hw + "/power1_cap") * 1e-6);
+    for (int pat = 0; pat < 3; ++pat) {
+        for (int i = 0; i < 1024; ++i)
+            h[i] = pat == 0 ? 0.f : pat == 1 ? 0.5f : (float)((i * 2654435761u) % 2000) / 1000.f - 1.0f;
+        hipMemcpy(in, h.data(), 1024 * 4, hipMemcpyHostToDevice);
+        const int iters = 4000, wg = 1024;            // 4 waves per SIMD
+        const double flop = (double)wg * 4 * iters * 16 * 8 * 16384;
+        for (int w = 0; w < 100; ++w) hipLaunchKernelGGL((k<8, 8>), dim3(wg), dim3(256), 0, 0, out, in, iters);   // reach the operating point
+        hipDeviceSynchronize();
+        double psum = 0, fsum = 0;
+        int ns = 0, launches = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            for (int w = 0; w < 8; ++w) hipLaunchKernelGGL((k<8, 8>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            launches += 8;
+            const long p = read_long(hw + "/power1_input"), f = read_long(hw + "/freq1_input");
+            if (p > 0 && f > 0) { psum += p * 1e-6; fsum += f * 1e-6; ++ns; }
+            hipDeviceSynchronize();
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double pf = flop * launches / dt / 1e15;
+        printf("%-9s %.3f PFLOP/s sustained  %7.1f W  %6.0f MHz  -> %.3f of the 2.5 PFLOP/s nominal, %.3f of the rate at that clock, %.2f pJ/FLOP\n",
+               pat == 0 ? "zeros" : pat == 1 ? "constant" : "random", pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, pf / 2.5,
+               ns ? pf / (2.5 * (fsum / ns) / 2400.0) : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
+    }
+    return 0;
+}

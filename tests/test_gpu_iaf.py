@@ -438,6 +438,44 @@ def test_phase_group_upsampler_matches_the_phase_major_form(monkeypatch):
             e.close()
 
 
+def test_part_timing_aid_accounts_for_the_call_and_leaves_results_alone():
+    """wn_profile_parts_*: HIP events where the parts of a generate call begin (bench.py's in-process kernel_us_per_call).  The
+    four parts of the default form are all present, non-negative and add up to about the wall time of the calls; the
+    recording does not change results; wn_profile_parts_only validates its mask and a restricted call still returns."""
+    import time
+    import torch
+    from oracle import wavenet_np as O
+    cfgd = load_json('parallel_wavenet.json')
+    w = O.synth_weights(O.HP(cfgd), 'student', seed=1234, init='tf')
+    eng = _engine(cfgd, w)
+    mel = np.random.RandomState(3).uniform(0, 1, [1, 384, 80]).astype(np.float32)
+    ref = eng.iaf_generate(mel, None, seed=5, want=('x',))['x']
+    for i in range(3):
+        eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
+    torch.cuda.synchronize()
+    eng.profile_parts_begin()
+    t0 = time.perf_counter()
+    got = eng.iaf_generate(mel, None, seed=5, want=('x',))['x']
+    for i in range(9):
+        eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms, n = eng.profile_parts_end()
+    assert n == 10 and sorted(ms) == sorted(eng.PROFILE_PARTS)
+    assert all(v >= 0 for v in ms.values()) and ms['cond_gemm'] > 0 and ms['residual_stack'] > ms['upsampler'] > 0
+    assert 0.5 * wall_ms <= sum(ms.values()) <= 1.2 * wall_ms
+    assert torch.equal(got, ref)
+    with pytest.raises(ValueError):
+        eng.profile_parts_only(0)
+    with pytest.raises(ValueError):
+        eng.profile_parts_only(16)
+    eng.profile_parts_only(4)                               # conditioning GEMM alone (power measurements)
+    eng.iaf_generate(mel, None, seed=5, want=('wav',), check_range=False)
+    eng.profile_parts_only(15)
+    assert torch.equal(eng.iaf_generate(mel, None, seed=5, want=('x',))['x'], ref)
+    eng.close()
+
+
 @pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused'])
 def test_repeated_calls_are_bit_identical_at_full_size(precision):
     """Six calls on the same inputs at the headline size (one utterance, 384 frames, 76 800 samples: 4 800 blocks x 60

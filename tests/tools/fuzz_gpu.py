@@ -18,6 +18,10 @@ hp = cfg.load_hparams(d)
 w = wts.synthetic_weights(hp, seed=int(rs.randint(1 << 20)), init='unit' if rs.rand() < 0.5 else 'tf')
 FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f32')
 engs = {p: Engine(d, precision=p).load_weights(w) for p in ('f16x3',) + FORMS}
+os.environ['WN_DC_NO_PG'] = '1'           # (read once, in wn_create) the upsampler's last layer as phase-major GEMM + interleave
+engs['f16x3-nopg'] = Engine(d, precision='f16x3').load_weights(w)
+os.environ.pop('WN_DC_NO_PG')
+FORMS = FORMS + ('f16x3-nopg',)
 n = 0
 while time.time() < t_end:
     B, F = int(rs.randint(1, 13)), int(rs.randint(3, 451))
