@@ -61,8 +61,7 @@ __device__ inline void ck_dma16(const unsigned* gsrc, unsigned lds_byte_addr) {
 //                tile is GATHERED from enc (64-byte runs: four residues x 16 B per decimated column) and holds the same
 //                128 samples' worth of operands, so the MFMA loop is identical.
 // Work list (round 5).  A UNIT is one sub-round: the eight waves of a workgroup take one row block each against one
-// staged tile.  Units are ordered (tile, kind, sub-round) -- natural tile j and decimated tile j cover the same 512-sample
-// neighbourhood of enc -- and every workgroup takes ONE CONTIGUOUS RANGE of them, equal to within one unit (4 800 units on
+// staged tile.  Units are ordered (kind, tile, sub-round) and every workgroup takes ONE CONTIGUOUS RANGE of them, equal to within one unit (4 800 units on
 // 256 workgroups at one utterance: 18 or 19 each, where rounds of whole (tile, 32-row-block chunk) tasks cost the fullest
 // workgroup 20).  A range crosses tile boundaries; the tile is restaged whenever (tile, kind) changes, by LDS-DMA: 16
 // requests of 1 KB per wave issued back to back and ONE wait, instead of four batches of global loads -> registers -> LDS
@@ -95,11 +94,23 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7ffffff0, 0x00020000);
     int staged_tile = -1, staged_kind = -1;
     // row block of this wave in unit u (clamped to the last one of its kind where a sub-round is short: `have` false)
+    // unit u -> (kind, tile, sub-round): all natural units first, then the decimated ones -- with contiguous eighths per XCD
+    // an XCD then works on ONE kind, and its L2 holds that kind's fragments (2 of the 4 MB) beside its stretch of enc
+    // (with the kinds interleaved per tile the counters showed 655 MB of fragment re-fetches per call)
+    const int64_t U_nat = (int64_t)ntiles * sr_nat;
+    auto unit_of = [&](int64_t u, int& tile, int& s) -> bool {
+        const bool dec = u >= U_nat;
+        const int64_t r = dec ? u - U_nat : u;
+        const int sr = dec ? sr_dec : sr_nat;
+        tile = (int)(r / sr);
+        s = (int)(r - (int64_t)tile * sr);
+        return dec;
+    };
     auto unit_rb = [&](int64_t u, bool& have) -> int {
-        const int tile = (int)(u / upt), su = (int)(u - (int64_t)tile * upt);
-        const bool dec = su >= sr_nat;
+        int tile, s;
+        const bool dec = unit_of(u, tile, s);
         const int p_end = dec ? R : n_nat;
-        const int pos = (dec ? n_nat : 0) + (dec ? su - sr_nat : su) * NW + wave;
+        const int pos = (dec ? n_nat : 0) + s * NW + wave;
         have = pos < p_end;
         return (int)order[have ? pos : p_end - 1];
     };
@@ -114,8 +125,8 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
         }
     }
     for (int64_t u = u_lo; u < u_hi; ++u) {
-        const int tile = (int)(u / upt), su = (int)(u - (int64_t)tile * upt);
-        const bool dec = su >= sr_nat;
+        int tile, su;
+        const bool dec = unit_of(u, tile, su);
         const int b = tile / tiles_per_row;
         const int j = tile - b * tiles_per_row;
         bool have, have_next;
