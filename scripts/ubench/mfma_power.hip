@@ -15,7 +15,9 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-template <int NACC, int NOP>
+// MODE 0: both operands change with every instruction; 1: A changes, B is held for 8 instructions; 2: B changes, A is
+// held for 8; 3: both held for 8 instructions (only the accumulator changes)
+template <int NACC, int NOP, int MODE = 0>
 __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters) {
     f4 acc[NACC];
     h8 a[NOP], b[NOP];
@@ -30,7 +32,11 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters)
 #pragma unroll
         for (int u = 0; u < 16; ++u)
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + i) % NOP], b[(u + 3 * i) % NOP], acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; ++i) {
+                const int ia = (MODE == 0 || MODE == 1) ? (u + i) % NOP : u % NOP;
+                const int ib = (MODE == 0 || MODE == 2) ? (u + 3 * i) % NOP : (u * 3) % NOP;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], acc[i], 0, 0, 0);
+            }
     }
     float s = 0;
 #pragma unroll
@@ -78,6 +84,34 @@ int main(int argc, char** argv) {
         printf("%-9s %.3f PFLOP/s sustained  %7.1f W  %6.0f MHz  -> %.3f of the 2.5 PFLOP/s nominal, %.3f of the rate at that clock, %.2f pJ/FLOP\n",
                pat == 0 ? "zeros" : pat == 1 ? "constant" : "random", pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, pf / 2.5,
                ns ? pf / (2.5 * (fsum / ns) / 2400.0) : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
+    }
+    // which operand changes between consecutive instructions (random data)
+    for (int mode = 0; mode < 4; ++mode) {
+        const int iters = 4000, wg = 1024;
+        const double flop = (double)wg * 4 * iters * 16 * 8 * 16384;
+        auto launch = [&]() {
+            if (mode == 0) hipLaunchKernelGGL((k<8, 8, 0>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 1) hipLaunchKernelGGL((k<8, 8, 1>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 2) hipLaunchKernelGGL((k<8, 8, 2>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else hipLaunchKernelGGL((k<8, 8, 3>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+        };
+        for (int w = 0; w < 100; ++w) launch();
+        hipDeviceSynchronize();
+        double psum = 0, fsum = 0;
+        int ns = 0, launches = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            for (int w = 0; w < 8; ++w) launch();
+            launches += 8;
+            const long p = read_long(hw + "/power1_input"), f = read_long(hw + "/freq1_input");
+            if (p > 0 && f > 0) { psum += p * 1e-6; fsum += f * 1e-6; ++ns; }
+            hipDeviceSynchronize();
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double pf = flop * launches / dt / 1e15;
+        printf("random, %-34s %.3f PFLOP/s  %7.1f W  %6.0f MHz  %.2f pJ/FLOP\n",
+               mode == 0 ? "A and B change every instruction" : mode == 1 ? "A changes, B held for 8" : mode == 2 ? "B changes, A held for 8" : "A and B held for 8",
+               pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
     }
     return 0;
 }
