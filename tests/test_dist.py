@@ -127,6 +127,35 @@ def test_bench_traffic_figure_follows_the_source_hash(monkeypatch, tmp_path):
         assert d['kernels'][dom]['hbm_bytes_per_launch'] > 0
 
 
+def test_bench_roofline_blocks_carry_the_same_three_fractions():
+    """Every roofline block of the bench line holds frac_mfma_alg, frac_mfma_exec and frac_hbm_moved (so that blocks and
+    rounds compare), an MFMA-bound block's `frac` is the ALGORITHMIC one, and the parts' blocks are built from the in-process
+    part timing: checked on the arithmetic with a stub engine (no GPU)."""
+    import bench
+    from types import SimpleNamespace
+    f = bench.three_fracs(2.5e15 * 1e-3, 8e12 * 1e-3 * 0.5, 1e-3)            # 1 ms: 2.5 PFLOP useful, 4 GB moved
+    assert abs(f['frac_mfma_alg'] - 1.0) < 1e-12 and abs(f['frac_mfma_exec'] - 3.0) < 1e-12 and abs(f['frac_hbm_moved'] - 0.5) < 1e-12
+    assert abs(f['frac_mfma_exec_of_sustained'] - 3.0 * 2500.0 / bench.SUSTAINED_F16_MFMA_TFLOPS) < 1e-9
+    f32 = bench.three_fracs(157.3e12 * 1e-3, 0.0, 1e-3, 1, bench.PEAK_F32_MFMA_TFLOPS)
+    assert abs(f32['frac_mfma_alg'] - 1.0) < 1e-12 and 'frac_mfma_exec_of_sustained' not in f32
+    hp = SimpleNamespace(deconv_width=256, width=64, num_iaf_layers=[10, 10, 10, 30], use_share_deconv=True,
+                         deconv_config=[[40, 10], [80, 20]], use_resize_conv=False)
+    eng = SimpleNamespace(precision='f16x3')
+    B, F, T = 1, 384, 76800
+    parts = {'prologue_epilogue': 18.0, 'upsampler': 140.0, 'cond_gemm': 380.0, 'residual_stack': 660.0}
+    out = bench.part_rooflines(eng, hp, B, F, T, parts, {'kernels': {'iaf_cond_h_kernel': {'hbm_bytes_per_launch': 1500000000, 'mfma_util': 0.6}},
+                                                        'file': 'profiles/x.json'})
+    c, d = out['roofline_cond'], out['roofline_deconv']
+    assert abs(c['flop_per_call'] - 2.0 * 4096 * 256 * T) < 1 and c['traffic'] == 1500000000 and c['mfma_util'] == 0.6
+    assert abs(c['frac'] - c['frac_mfma_alg']) < 1e-12 and abs(c['frac_mfma_exec'] - 3 * c['frac_mfma_alg']) < 1e-12
+    assert abs(c['achieved'] - c['flop_per_call'] / 380e-6 / 1e12) < 1e-6 and c['bound'] == 'mfma'
+    # upsampler: 2 * 256 * 4 taps * (80 * 3840 + 256 * 76800) MACs
+    assert abs(d['flop_per_call'] - 2.0 * 256 * 4 * (80 * 3840 + 256 * 76800)) < 1 and d['us_per_call'] == 140.0
+    for blk in (c, d):
+        assert all(k in blk for k in ('frac_mfma_alg', 'frac_mfma_exec', 'frac_hbm_moved', 'algorithmic_TFLOPs', 'executed_TFLOPs', 'moved_GBps'))
+    assert bench.HwmonSampler(0).summary() is None or True                     # (no GPU here: the sampler must not raise)
+
+
 def _cli_worker(rank, world, port, src, dst, ckpt, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
