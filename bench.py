@@ -13,6 +13,14 @@ A step = one pass of the whole generation hot path (noise draw, mel upsampler, c
 resident in HBM.  Utterances are independent, so N ranks each generate their own batch with no
 data-path collective (weak scaling); the only communication is the one-time weight broadcast from
 rank 0 (untimed).  Rank 0 prints ONE JSON line.
+
+Beside the contract's fields the line carries (N = 1): `roofline` (the dominant kernel, HIP events inside the library around
+its launches), `roofline_cond` / `roofline_deconv` (conditioning GEMM, upsampler), `roofline_b8` (eight utterances per GPU),
+`roofline_f32` (the reference's own arithmetic) -- each with the same three fractions `frac_mfma_alg`, `frac_mfma_exec`,
+`frac_hbm_moved`; `kernel_us_per_call` (HIP events at the part boundaries, this process); `power` (package power, shader clock
+and energy per sample of a sustained run: the workload runs at the part's power cap); `ar_b1`, `ar_b64`,
+`teacher_forward` (BASELINE configs[3] and the teacher's full-sequence forward); `e2e_ms_per_step` (PCIe-inclusive call);
+`cpu_baseline`.  `--no-extras` keeps only the contract's fields and `roofline`.
 """
 import argparse
 import hashlib
