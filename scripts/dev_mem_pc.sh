@@ -1,5 +1,6 @@
 #!/bin/bash
-# producer -> consumer windows through the memory side (scripts/ubench/mem_power.hip, `pc` mode): run on the GPU box
+# energy ubenches on the GPU box: producer -> consumer windows through the memory side (scripts/ubench/mem_power.hip, `pc` mode) and the
+# non-matrix instruction classes (scripts/ubench/lds_valu_power.hip).  usage: dev_mem_pc.sh [pc|lv|all]
 set -u
 mkdir -p gpurun_out
 HW=$(python - <<'PY'
@@ -11,5 +12,12 @@ print(hw[0] if hw else '')
 PY
 )
 echo "hwmon $HW"
-cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o /tmp/mem_power "$GRAFT_REPO_ROOT/scripts/ubench/mem_power.hip" && cd "$GRAFT_REPO_ROOT"
-timeout 300 /tmp/mem_power "$HW" 2.0 pc 2>&1 | tee gpurun_out/mem_pc.txt
+WHAT=${1:-all}
+if [ "$WHAT" != lv ]; then
+  cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o /tmp/mem_power "$GRAFT_REPO_ROOT/scripts/ubench/mem_power.hip" && cd "$GRAFT_REPO_ROOT"
+  timeout 300 /tmp/mem_power "$HW" 2.0 pc 2>&1 | tee gpurun_out/mem_pc.txt
+fi
+if [ "$WHAT" != pc ]; then
+  cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o /tmp/lds_valu_power "$GRAFT_REPO_ROOT/scripts/ubench/lds_valu_power.hip" && cd "$GRAFT_REPO_ROOT"
+  timeout 300 /tmp/lds_valu_power "$HW" 2.5 2>&1 | tee gpurun_out/lds_valu_power.txt
+fi
