@@ -44,6 +44,58 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the same loop on the bf16 and fp8 forms of the instruction (random operands): is the energy in the multiplier width?
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_bf16(float* out, const float* in, int iters) {
+    f4 acc[8];
+    s8 a[8], b[8];
+    for (int o = 0; o < 8; ++o)
+        for (int i = 0; i < 8; ++i) {
+            a[o][i] = (short)(__float_as_uint(in[(threadIdx.x + 17 * o + i) & 1023]) >> 16);
+            b[o][i] = (short)(__float_as_uint(in[(threadIdx.x + 29 * o + 8 + i) & 1023]) >> 16);
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a[(u + i) % 8]), __builtin_bit_cast(b8, b[(u + 3 * i) % 8]), acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// fp16 operands whose low mantissa bits are zero (`keep` of the 10 stored bits kept): does a sparser multiplicand cost less?
+template <int KEEP>
+__global__ __launch_bounds__(256) void k_trunc(float* out, const float* in, int iters) {
+    f4 acc[8];
+    h8 a[8], b[8];
+    for (int o = 0; o < 8; ++o)
+        for (int i = 0; i < 8; ++i) {
+            _Float16 x = (_Float16)in[(threadIdx.x + 17 * o + i) & 1023], y = (_Float16)in[(threadIdx.x + 29 * o + 8 + i) & 1023];
+            unsigned short xb = __builtin_bit_cast(unsigned short, x) & (unsigned short)(0xffffu << (10 - KEEP));
+            unsigned short yb = __builtin_bit_cast(unsigned short, y) & (unsigned short)(0xffffu << (10 - KEEP));
+            a[o][i] = __builtin_bit_cast(_Float16, xb);
+            b[o][i] = __builtin_bit_cast(_Float16, yb);
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + i) % 8], b[(u + 3 * i) % 8], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static long read_long(const std::string& p) {
     FILE* f = fopen(p.c_str(), "r");
     if (!f) return -1;
@@ -85,15 +137,19 @@ int main(int argc, char** argv) {
                pat == 0 ? "zeros" : pat == 1 ? "constant" : "random", pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, pf / 2.5,
                ns ? pf / (2.5 * (fsum / ns) / 2400.0) : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
     }
-    // which operand changes between consecutive instructions (random data)
-    for (int mode = 0; mode < 4; ++mode) {
+    // which operand changes between consecutive instructions (random data); modes 4..7: bf16 operands, fp16 operands with 7 / 4 / 1 stored mantissa bits
+    for (int mode = (argc > 3 ? 4 : 0); mode < (argc > 3 ? 8 : 4); ++mode) {
         const int iters = 4000, wg = 1024;
         const double flop = (double)wg * 4 * iters * 16 * 8 * 16384;
         auto launch = [&]() {
             if (mode == 0) hipLaunchKernelGGL((k<8, 8, 0>), dim3(wg), dim3(256), 0, 0, out, in, iters);
             else if (mode == 1) hipLaunchKernelGGL((k<8, 8, 1>), dim3(wg), dim3(256), 0, 0, out, in, iters);
             else if (mode == 2) hipLaunchKernelGGL((k<8, 8, 2>), dim3(wg), dim3(256), 0, 0, out, in, iters);
-            else hipLaunchKernelGGL((k<8, 8, 3>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 3) hipLaunchKernelGGL((k<8, 8, 3>), dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 4) hipLaunchKernelGGL(k_bf16, dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 5) hipLaunchKernelGGL(k_trunc<7>, dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 6) hipLaunchKernelGGL(k_trunc<4>, dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else hipLaunchKernelGGL(k_trunc<1>, dim3(wg), dim3(256), 0, 0, out, in, iters);
         };
         for (int w = 0; w < 100; ++w) launch();
         hipDeviceSynchronize();
@@ -110,7 +166,8 @@ int main(int argc, char** argv) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const double pf = flop * launches / dt / 1e15;
         printf("random, %-34s %.3f PFLOP/s  %7.1f W  %6.0f MHz  %.2f pJ/FLOP\n",
-               mode == 0 ? "A and B change every instruction" : mode == 1 ? "A changes, B held for 8" : mode == 2 ? "B changes, A held for 8" : "A and B held for 8",
+               mode == 0 ? "A and B change every instruction" : mode == 1 ? "A changes, B held for 8" : mode == 2 ? "B changes, A held for 8" : mode == 3 ? "A and B held for 8"
+               : mode == 4 ? "bf16 operands" : mode == 5 ? "fp16, 7 mantissa bits kept" : mode == 6 ? "fp16, 4 mantissa bits kept" : "fp16, 1 mantissa bit kept",
                pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
     }
     return 0;
