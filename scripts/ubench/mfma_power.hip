@@ -96,6 +96,34 @@ __global__ __launch_bounds__(256) void k_trunc(float* out, const float* in, int 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the 32x32x16 shape of the same instruction family (4 accumulators of 16 registers): same FLOP rate, half the operand words per FLOP
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_32(float* out, const float* in, int iters) {
+    f16v acc[4];
+    h8 a[8], b[8];
+    for (int o = 0; o < 8; ++o)
+        for (int i = 0; i < 8; ++i) {
+            a[o][i] = (_Float16)in[(threadIdx.x + 17 * o + i) & 1023];
+            b[o][i] = (_Float16)in[(threadIdx.x + 29 * o + 8 + i) & 1023];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(u + i) % 8], b[(u + 3 * i) % 8], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static long read_long(const std::string& p) {
     FILE* f = fopen(p.c_str(), "r");
     if (!f) return -1;
@@ -138,7 +166,7 @@ int main(int argc, char** argv) {
                ns ? pf / (2.5 * (fsum / ns) / 2400.0) : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
     }
     // which operand changes between consecutive instructions (random data); modes 4..7: bf16 operands, fp16 operands with 7 / 4 / 1 stored mantissa bits
-    for (int mode = (argc > 3 ? 4 : 0); mode < (argc > 3 ? 8 : 4); ++mode) {
+    for (int mode = (argc > 3 ? 4 : 0); mode < (argc > 3 ? 9 : 4); ++mode) {
         const int iters = 4000, wg = 1024;
         const double flop = (double)wg * 4 * iters * 16 * 8 * 16384;
         auto launch = [&]() {
@@ -149,7 +177,8 @@ int main(int argc, char** argv) {
             else if (mode == 4) hipLaunchKernelGGL(k_bf16, dim3(wg), dim3(256), 0, 0, out, in, iters);
             else if (mode == 5) hipLaunchKernelGGL(k_trunc<7>, dim3(wg), dim3(256), 0, 0, out, in, iters);
             else if (mode == 6) hipLaunchKernelGGL(k_trunc<4>, dim3(wg), dim3(256), 0, 0, out, in, iters);
-            else hipLaunchKernelGGL(k_trunc<1>, dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else if (mode == 7) hipLaunchKernelGGL(k_trunc<1>, dim3(wg), dim3(256), 0, 0, out, in, iters);
+            else hipLaunchKernelGGL(k_32, dim3(wg), dim3(256), 0, 0, out, in, iters);      // 16 x 4 x 32 768 FLOP per iteration = the same
         };
         for (int w = 0; w < 100; ++w) launch();
         hipDeviceSynchronize();
@@ -167,7 +196,7 @@ int main(int argc, char** argv) {
         const double pf = flop * launches / dt / 1e15;
         printf("random, %-34s %.3f PFLOP/s  %7.1f W  %6.0f MHz  %.2f pJ/FLOP\n",
                mode == 0 ? "A and B change every instruction" : mode == 1 ? "A changes, B held for 8" : mode == 2 ? "B changes, A held for 8" : mode == 3 ? "A and B held for 8"
-               : mode == 4 ? "bf16 operands" : mode == 5 ? "fp16, 7 mantissa bits kept" : mode == 6 ? "fp16, 4 mantissa bits kept" : "fp16, 1 mantissa bit kept",
+               : mode == 4 ? "bf16 operands" : mode == 5 ? "fp16, 7 mantissa bits kept" : mode == 6 ? "fp16, 4 mantissa bits kept" : mode == 7 ? "fp16, 1 mantissa bit kept" : "fp16, 32x32x16 shape",
                pf, ns ? psum / ns : 0.0, ns ? fsum / ns : 0.0, ns ? (psum / ns) / (pf * 1e15) * 1e12 : 0.0);
     }
     return 0;
