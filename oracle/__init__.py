@@ -5,12 +5,32 @@ may import, call, link or execute anything under `oracle/`.  Only `tests/`,
 `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it, and only
 as the checker / the timed CPU baseline.
 
-PARITY UNPINNED: the reference (bfs18/nsynth_wavenet) is TensorFlow-1.x Python;
-TensorFlow is not installed here or on the GPU box and the reference's own tests
-print instead of asserting, so no TF-derived golden vector exists.  What IS held
-by the reference and checked here, row by row of SURVEY.md section 8(a):
+PARITY -- what pins this oracle (round 5).  The reference (bfs18/nsynth_wavenet) is TensorFlow-1.x Python and
+TensorFlow is not installed here or on the GPU box, and the reference's own tests print instead of asserting, so there
+is NO TENSORFLOW-PRODUCED VECTOR.  What exists instead, strongest first:
 
-  reference-pinned
+  1. REFERENCE CODE EXECUTED (tests/golden/make_ref_float.py -> tests/golden/ref_float.npz, tests/test_ref_float.py).
+     The reference's wavenet/masked.py, wavenet.py, parallel_wavenet.py, loss_func.py, fastgen.py, parallelgen.py and
+     auxilaries/utils.py are imported UNMODIFIED from /root/reference and driven the way eval_parallel_wavenet.py /
+     eval_wavenet.py drive them (parallelgen.synthesis; fastgen.load_deconv_stack, load_fastgen, synthesis,
+     calculate_cond_vars; Wavenet.encode_signal + feed_forward), with `import tensorflow` resolved to
+     tests/golden/tf_standin.py: a numpy evaluator of the ~70 TensorFlow primitives those files call (graph, session,
+     placeholders, variable scopes, Saver.restore, conv2d, conv2d_transpose, pad / slice / reshape / transpose,
+     FIFOQueue, random_uniform, ...).  Eleven cases (the seven of make_golden.py plus weight-norm + resize-conv student
+     and teacher, and a use_teacher_deconv student), each in float64 and float32.  This oracle agrees with those runs to
+     float64 rounding (<= 1e-12 of the range) on x / mean_tot / scale_tot / log_scale_tot, the upsampler output, the
+     full-sequence teacher, cond_vars and every network output of the free-running incremental loop; the sampled index
+     streams are IDENTICAL; the variables the reference graphs create and the checkpoint keys their Savers request are
+     exactly weights.expected_variables / checkpoint_keys.  Rows a1-a7, a9, a10, a12-a14 of SURVEY.md section 8.
+     PINNED by this: everything the reference's own code decides (names, scopes, EMA keys, time_to_batch dilation
+     arithmetic, causal padding, tap order, centre crop, gate order, residual / skip wiring, flow head, mean_tot /
+     scale_tot recursion and clips, queue discipline, sampler formulas, quantiser, the driver loops down to the wav files).
+     NOT pinned: TensorFlow's kernels themselves -- tf_standin.py restates their documented semantics (SAME-padding
+     arithmetic of conv2d_transpose, nearest-neighbour resize, l2_normalize epsilon, softplus) -- float32 rounding order
+     inside a TF kernel, and TF's random generators (randoms are injected; the 'ce' head's categorical draw is DEFINED as
+     inverse-CDF from one uniform).  That remainder is why this header does not say "TensorFlow-pinned".
+  2. REFERENCE NUMPY EXECUTED: auxilaries/utils.py's pure-numpy codecs (rows a8 / a11; tests/golden/make_ref_codec.py).
+  3. REFERENCE-HELD FACTS:
     a8   _clip_quant_scale / cast_quantize: every non-mu-law output wav the reference commits lies on the
          2^-15 grid inside [-1, 1-2^-15] and is a fixed point of the restated quantiser
          (tests/golden/ref_fixture_facts.npz, tests/test_oracle.py::test_reference_outputs_on_grid_match_clip_quant)
@@ -24,7 +44,6 @@ by the reference and checked here, row by row of SURVEY.md section 8(a):
          tests/test_gpu_iaf.py::test_flow_head_scale_path_on_test_scale_draws).  The statistics the reference
          prints beside it (scale.m 0.38296, scale.std 0.61160) are a log line of a weight-normalised TF model
          (they are the moments of parameters ~ N(-0.01, 0.93^2), not of N(0,1) draws): regime check only.
-  restatement-only (checked against the reference's own invariants K1/K2/K3, against an independent torch-CPU
-  implementation that shares no code -- oracle/torch_ref.py --, against TF op definitions, never against TF output)
-    a1-a5, a7 (arithmetic), a9, a10, a13, a14 and the float values of a6.
+  4. the reference's own invariants K1 / K2 / K3 and an independent torch-CPU implementation (oracle/torch_ref.py).
+  Still restatement-only: the mel featuriser (oracle/mel_np.py: librosa is absent).
 """

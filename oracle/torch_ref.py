@@ -1,6 +1,6 @@
 """Independent torch-CPU implementation of the IAF generation path (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED (see oracle/__init__.py).  Two purposes:
+PARITY: see oracle/__init__.py (held to the reference's own code through oracle/wavenet_np.py; no TensorFlow run).  Two purposes:
   * an implementation of the same math built from torch's own conv primitives
     (F.conv1d with dilation, F.conv_transpose1d) so that oracle/wavenet_np.py is
     checked by something that shares no code with it;

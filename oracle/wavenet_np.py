@@ -1,7 +1,8 @@
 """numpy restatement of the nsynth_wavenet generation path (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED (see oracle/__init__.py): restated from the closed forms of the
-reference's TensorFlow-op compositions, not validated against a TF run.
+PARITY (see oracle/__init__.py): restated from the closed forms of the reference's TensorFlow-op compositions;
+held to the reference's OWN code executed over a numpy evaluator of the TensorFlow primitives (tests/test_ref_float.py:
+float64 rounding, identical index streams); not validated against a TensorFlow run (TensorFlow kernel semantics unpinned).
 
 Every function cites the reference file:line it follows (paths relative to the
 reference tree).  All arrays are [B, T, C] channels-last like the reference.

@@ -1,0 +1,330 @@
+"""Float-path vectors produced by the REFERENCE'S OWN Python, executed in the build container over a numpy evaluator
+for the TensorFlow primitives (tests/golden/tf_standin.py -- read its header for what that does and does not pin).
+
+Run in the build container only (needs /root/reference; nothing of it travels -- only the .npz below):
+    python tests/golden/make_ref_float.py
+Writes tests/golden/ref_float.npz.
+
+For every case of tests/golden/make_golden.py (same configs, same mel / random seeds, same synthetic weights) the
+reference's files are imported unmodified from /root/reference and DRIVEN THE WAY THE REFERENCE DRIVES THEM:
+
+  student  wavenet/parallelgen.py: load_parallelgen() builds ParallelWavenet.feed_forward + _clip_quant_scale on a
+           placeholder; synthesis() restores the checkpoint through its own Saver map, runs the session and writes the
+           wav files.  Recorded: the noise the graph drew (injected uniforms / normals), mean_tot, scale_tot, the
+           pre-quantisation x = rand_input * scale_tot + mean_tot, the quantised audio, the wav file synthesis() wrote,
+           a strided sample of the upsampler output, the variables the graph created and the checkpoint keys its
+           Saver asked for.
+  teacher  wavenet/fastgen.py: load_deconv_stack() (the encoding), Wavenet.encode_signal + Wavenet.feed_forward on a
+           forced waveform (the full-sequence teacher), Fastgen.cond_vars, load_fastgen() + the sample-by-sample loop
+           of synthesis() (FIFO queues, push ops, the de-quantised feedback) with the sampler's randoms injected;
+           synthesis() itself is run as written and the wav files it writes are recorded.
+
+Each case is evaluated twice: with tf.float32 mapped to float64 (master copy, `*_f64`) and to float32 (the arithmetic
+TensorFlow would run, `*_f32`).  The checkpoint the reference restores from is written by the PRODUCT's
+nsynth_wavenet_amd.weights.save_checkpoint, so a key the reference's Saver asks for and the product does not write
+fails here.
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+from argparse import Namespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+OUT = os.path.join(HERE, 'ref_float.npz')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import tf_standin as tf  # noqa: E402
+from oracle import wavenet_np as O  # noqa: E402   (synthetic weights only: the same dict the other goldens use)
+from nsynth_wavenet_amd import weights as wts, config as cfgmod  # noqa: E402   (checkpoint writer under test)
+
+
+class _Inert(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Inert(self.__name__ + '.' + name)
+
+    def __call__(self, *a, **k):
+        raise RuntimeError('placeholder for an absent dependency was CALLED: ' + self.__name__)
+
+
+def import_reference():
+    tf.install()
+    for name in ('librosa', 'librosa.filters'):
+        sys.modules[name] = _Inert(name)
+    sys.path.insert(0, REF)
+    import importlib
+    mods = {}
+    for m in ('wavenet.masked', 'wavenet.loss_func', 'wavenet.wavenet', 'wavenet.parallel_wavenet', 'wavenet.fastgen',
+              'wavenet.parallelgen', 'auxilaries.utils'):
+        mods[m.split('.')[1]] = importlib.import_module(m)
+        assert os.path.realpath(mods[m.split('.')[1]].__file__).startswith(REF)
+    return Namespace(**mods)
+
+
+class TableSource(object):
+    """random_source for the stand-in: node index -> function(step) -> array; one step per evaluation of the node."""
+
+    def __init__(self, table):
+        self.table, self.count = table, {}
+
+    def __call__(self, index, kind, shape, run_no, lo, hi):
+        step = self.count.get(index, 0)
+        self.count[index] = step + 1
+        v = np.asarray(self.table[index](step))
+        assert list(v.shape) == list(shape), (index, v.shape, shape)
+        if kind == 'uniform':
+            assert v.min() >= lo and v.max() < hi, (index, v.min(), v.max(), lo, hi)
+        return v
+
+
+def reference_hparams(cfgd, kind):
+    """The reference's own JSON of that model (it carries the training keys the classes read in __init__: num_iters,
+    wave_length), overlaid with the case's settings -- Namespace(**configs) as eval_*.py:28-30 build it."""
+    lt = cfgd['loss_type']
+    name = ('parallel_wavenet_gauss.json' if lt == 'gauss' else 'parallel_wavenet.json') if kind == 'student' \
+        else 'wavenet_{}.json'.format(lt)
+    with open(os.path.join(REF, 'config_jsons', name)) as f:
+        d = json.load(f)
+    d.update(cfgd)
+    return Namespace(**d)
+
+
+def var_list():
+    return [(v.name[:-2], list(v.sample.shape)) for v in tf.trainable_variables()]
+
+
+def find_bias_add(root, bias_name):
+    """The bias_add node of the variable scope `bias_name` upstream of `root` (the reference returns only the sample)."""
+    seen, stack = set(), [root]
+    while stack:
+        n = stack.pop()
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        if n.name == 'bias_add' and n.inputs[1].kind == 'var' and n.inputs[1].full == bias_name:
+            return n
+        stack.extend(n.inputs)
+    raise KeyError(bias_name)
+
+
+def student_case(R, g, out, tag, tmp, w=None):
+    cfgd = json.loads(str(g['cfg_json']))
+    hp_o = O.HP(cfgd)
+    if w is None:
+        w = O.synth_weights(hp_o, 'student', seed=int(g['seed']), init=str(g['init']))
+    ckpt = wts.save_checkpoint(os.path.join(tmp, tag + '.npz'), w, cfgmod.load_hparams(cfgd))
+    mel = g['mel']
+    B, F, _ = mel.shape
+    T = O.iaf_length(F, hp_o)
+    rs = np.random.RandomState(12346)            # make_golden.iaf_case draws its noise from the same stream
+    gauss = cfgd['loss_type'] == 'gauss'
+    draw = rs.standard_normal([B, T]) if gauss else rs.uniform(1e-5, 1 - 1e-5, [B, T])
+    draw = draw.astype(np.float32).astype(np.float64)          # float32-valued, so both arithmetics see the same numbers
+    for fl, dt in (('f64', np.float64), ('f32', np.float32)):
+        tf.set_float(dt)
+        tf.Saver.requested = []
+        hparams = reference_hparams(cfgd, 'student')
+        # -- parallelgen.synthesis as written (restores through its own Saver map, writes the wav files)
+        tf.set_random_source(TableSource({0: lambda step: draw}))
+        paths = [os.path.join(tmp, '{}_{}_{}.wav'.format(tag, fl, b)) for b in range(B)]
+        R.parallelgen.synthesis(hparams, mel, paths, ckpt)
+        from scipy.io import wavfile
+        wav_files = np.stack([wavfile.read(p)[1] for p in paths])
+        requested = list(tf.Saver.requested[-1])
+        # -- the same graph once more, to fetch what synthesis() does not return
+        tf.set_random_source(TableSource({0: lambda step: draw}))
+        with tf.Graph().as_default(), tf.Session() as sess:
+            fg = R.parallelgen.load_parallelgen(hparams, B, F, mel.shape[2])
+            vl = var_list()
+            pw = R.parallel_wavenet.ParallelWavenet(hparams)
+            share = pw.use_share_deconv or pw.use_teacher_deconv
+            enc_t = pw.deconv_stack({'mel': fg['mel_in']}, name='iaf_share' if share else 'iaf_1')['encoding']
+            assert var_list() == vl                            # AUTO_REUSE: no new variables
+            tf_vars = tf.trainable_variables()                 # the restore map of parallelgen.py:29-41, from its own helpers
+            filtered = pw.filter_update_variables(tf_vars)
+            var_dict = R.fastgen.get_ema_shadow_dict(filtered)
+            var_dict.update(R.parallelgen.get_default_shadow_dict([v for v in tf_vars if v not in filtered]))
+            tf.train.Saver(var_dict, reshape=True).restore(sess, ckpt)
+            assert sorted(tf.Saver.requested[-1]) == sorted(requested)
+            vals = sess.run({k: fg[k] for k in ('x', 'mean_tot', 'scale_tot', 'log_scale_tot', 'rand_input')} |
+                            {'enc': enc_t}, feed_dict={fg['mel_in']: mel})
+        assert np.array_equal(wav_files.astype(np.float64), vals['x'].astype(np.float64)), 'synthesis() wav != fetched x'
+        x_pre = vals['rand_input'] * vals['scale_tot'] + vals['mean_tot']      # parallel_wavenet.py:326 (new_x)
+        for k in ('mean_tot', 'scale_tot', 'log_scale_tot', 'rand_input'):
+            out['{}/{}_{}'.format(tag, k, fl)] = vals[k]
+        out['{}/x_{}'.format(tag, fl)] = x_pre
+        out['{}/wav_{}'.format(tag, fl)] = vals['x'].astype(np.float32)
+        out['{}/enc_sub_{}'.format(tag, fl)] = vals['enc'][:, ::7, ::5]
+        print(tag, fl, 'T', T, '|x| max', float(np.abs(x_pre).max()), 'scale_tot', float(vals['scale_tot'].min()),
+              float(vals['scale_tot'].max()))
+    out[tag + '/vars'] = np.array(json.dumps(vl))
+    out[tag + '/ckpt_keys'] = np.array(json.dumps(requested))
+    out[tag + '/kind'] = np.array('student')
+
+
+def teacher_case(R, g, out, tag, tmp, w=None):
+    cfgd = json.loads(str(g['cfg_json']))
+    hp_o = O.HP(cfgd)
+    if w is None:
+        w = O.synth_weights(hp_o, 'teacher', seed=int(g['seed']), init=str(g['init']))
+    ckpt = wts.save_checkpoint(os.path.join(tmp, tag + '.npz'), w, cfgmod.load_hparams(cfgd))
+    mel, rnd, forced = g['mel'], g['rnd'], g['forced']
+    B, F, n_mel = mel.shape
+    Tn = forced.shape[1]
+    M = cfgd.get('mol_mix', 10)
+    lt = cfgd['loss_type']
+    if lt == 'mol':
+        table = {0: lambda t: rnd[t][:, :M].reshape(B, 1, M), 1: lambda t: rnd[t][:, M].reshape(B, 1)}
+    elif lt == 'gauss':
+        table = {0: lambda t: rnd[t][:, 0].reshape(B, 1)}
+    else:
+        table = {0: lambda t: rnd[t][:, 0].reshape(1, B, 1)}
+    Q = 256 if cfgd['use_mu_law'] else 65536
+    from scipy.io import wavfile
+    for fl, dt in (('f64', np.float64), ('f32', np.float32)):
+        tf.set_float(dt)
+        tf.Saver.requested = []
+        hparams = reference_hparams(cfgd, 'teacher')
+        ema = R.fastgen.get_ema_shadow_dict
+        # -- the encoding: fastgen.encode without its librosa front end (load_deconv_stack + the restore lines)
+        with tf.Graph().as_default(), tf.Session() as sess:
+            ds = R.fastgen.load_deconv_stack(hparams, B, F, n_mel)
+            tf.train.Saver(ema(tf.trainable_variables())).restore(sess, ckpt)
+            enc = sess.run(ds['encoding'], feed_dict={ds['mel_in']: mel})
+        assert enc.shape[1] == Tn
+        # -- the full-sequence teacher on a forced waveform (wavenet.py:157-291)
+        with tf.Graph().as_default(), tf.Session() as sess:
+            # dropout off the way the reference switches it off for a teacher it evaluates (train_parallel_wavenet.py:37)
+            wn = R.wavenet.Wavenet(Namespace(**dict(vars(hparams), use_as_teacher=True)))
+            wav_ph = tf.placeholder(tf.float32, [B, Tn])
+            mel_ph = tf.placeholder(tf.float32, [B, F, n_mel])
+            es = wn.encode_signal({'wav': wav_ph})
+            ff = wn.feed_forward({'mel': mel_ph, 'wav_scaled': es['wav_scaled']})
+            vl = var_list()
+            tf.train.Saver(ema(tf.trainable_variables())).restore(sess, ckpt)
+            requested_ff = list(tf.Saver.requested[-1])
+            out_forced, enc_ff = sess.run([ff['out_params'], ff['encoding']], feed_dict={wav_ph: forced, mel_ph: mel})
+        assert np.array_equal(enc_ff, enc)
+        # -- Fastgen.cond_vars through fastgen.calculate_cond_vars as written
+        cond = R.fastgen.calculate_cond_vars(hparams, enc, ckpt)
+        # -- the incremental sampler, free running: synthesis() as written ...
+        enc32 = enc.astype(np.float32)
+        tf.set_random_source(TableSource(table))
+        paths = [os.path.join(tmp, '{}_{}_{}.wav'.format(tag, fl, b)) for b in range(B)]
+        R.fastgen.synthesis(hparams, enc32, paths, ckpt)
+        wav_files = np.stack([wavfile.read(p)[1] for p in paths])
+        requested_fg = list(tf.Saver.requested[-1])
+        # ... and its loop once more (fastgen.py:128-169) with the network output of every step fetched as well
+        tf.set_random_source(TableSource(table))
+        with tf.Graph().as_default(), tf.Session() as sess:
+            fg = R.fastgen.load_fastgen(hparams, B)
+            vl_fg = var_list()
+            out_node = find_bias_add(fg['sample'], 'out2/biases')
+            tf.train.Saver(ema(tf.trainable_variables())).restore(sess, ckpt)
+            sess.run(fg['init_ops'])
+            audio = np.zeros([B, 1])
+            idx = np.zeros([B, Tn], np.int32)
+            outs = []
+            wav = np.zeros([B, Tn], np.float32)
+            for t in range(Tn):
+                q, o, _ = sess.run([fg['sample'], out_node, fg['push_ops']],
+                                   feed_dict={fg['wav_in']: audio, fg['encoding_in']: enc32[:, t, :]})
+                audio = (R.utils.inv_mu_law_numpy(q) if cfgd['use_mu_law'] else R.utils.inv_cast_quantize_numpy(q, Q))
+                idx[:, t] = q[:, 0]
+                wav[:, t] = audio[:, 0]
+                outs.append(o)
+        assert np.array_equal(wav, wav_files), 'synthesis() wav != the re-run loop'
+        # -- teacher forced through the incremental graph: K1 (incremental == full sequence) on the reference itself
+        with tf.Graph().as_default(), tf.Session() as sess:
+            tf.set_random_source(TableSource(table))
+            fg = R.fastgen.load_fastgen(hparams, B)
+            out_node = find_bias_add(fg['sample'], 'out2/biases')
+            tf.train.Saver(ema(tf.trainable_variables())).restore(sess, ckpt)
+            sess.run(fg['init_ops'])
+            prev = np.zeros([B, 1])
+            inc = []
+            for t in range(Tn):
+                o, _ = sess.run([out_node, fg['push_ops']], feed_dict={fg['wav_in']: prev, fg['encoding_in']: enc[:, t, :]})
+                inc.append(o)
+                prev = forced[:, t:t + 1]
+        inc = np.stack(inc, axis=1)
+        k1 = float(np.abs(inc - out_forced).max())
+        out['{}/enc_{}'.format(tag, fl)] = enc
+        out['{}/out_forced_{}'.format(tag, fl)] = out_forced
+        out['{}/free_idx_{}'.format(tag, fl)] = idx
+        out['{}/free_wav_{}'.format(tag, fl)] = wav
+        out['{}/free_out_{}'.format(tag, fl)] = np.stack(outs, axis=1)
+        out['{}/k1_{}'.format(tag, fl)] = np.array(k1)
+        names = sorted(cond.keys())
+        out['{}/cond_sub_{}'.format(tag, fl)] = np.stack([cond[k][:, ::5, ::7] for k in names if k != 'mel_cond_out1'])
+        out['{}/cond_out1_sub_{}'.format(tag, fl)] = cond['mel_cond_out1'][:, ::5, ::7]
+        print(tag, fl, 'Tn', Tn, 'K1 (incremental vs full sequence, reference code)', k1)
+    assert set(requested_fg) < set(requested_ff) and all('trans_conv' in k or 'resize_conv' in k
+                                                         for k in set(requested_ff) - set(requested_fg))
+    assert all(v in vl for v in vl_fg)
+    out[tag + '/ckpt_keys_fastgen'] = np.array(json.dumps(requested_fg))
+    out[tag + '/vars'] = np.array(json.dumps(vl))
+    out[tag + '/ckpt_keys'] = np.array(json.dumps(requested_ff))
+    out[tag + '/kind'] = np.array('teacher')
+
+
+def repo_cfg(name):
+    with open(os.path.join(ROOT, 'config_jsons', name)) as f:
+        return json.load(f)
+
+
+def extra_cases(R, out, tmp):
+    """Rows a13 / a14 beyond make_golden's cases: weight normalisation + resize-conv upsampler (student and teacher), and a
+    student on the teacher's upsampler (use_teacher_deconv: those variables are restored under their RAW names,
+    parallelgen.py:29-41).  Weights: nsynth_wavenet_amd.weights.synthetic_weights(hp, seed=9, init='unit'); the inputs are
+    stored in the fixture."""
+    small = dict(width=128, skip_width=64, deconv_width=64, num_layers=7, num_stages=3, deconv_config=[[8, 2], [12, 4]])
+    cases = [
+        ('iaf_wn_resize', 'student', dict(repo_cfg('parallel_wavenet.json'), use_weight_norm=True, use_resize_conv=True,
+                                          upsample_act='tanh', num_iaf_layers=[10, 10]), 1, 6),
+        ('iaf_teacher_deconv', 'student', dict(repo_cfg('parallel_wavenet.json'), use_share_deconv=False,
+                                               use_teacher_deconv=True, num_iaf_layers=[10]), 2, 6),
+        ('ar_wn_resize', 'teacher', dict(repo_cfg('wavenet_mol.json'), use_weight_norm=True, use_resize_conv=True,
+                                         upsample_act='tanh', **small), 2, 5),
+    ]
+    for tag, kind, cfgd, B, F in cases:
+        hp = cfgmod.load_hparams(cfgd)
+        w = wts.synthetic_weights(hp, seed=9, init='unit')
+        g = {'cfg_json': np.array(json.dumps(cfgd)), 'seed': np.array(9), 'init': np.array('unit'),
+             'mel': np.random.RandomState(21).uniform(0, 1, [B, F, 80]).astype(np.float32)}
+        if kind == 'teacher':
+            Tn = F * int(np.prod([c[1] for c in cfgd['deconv_config']]))
+            n_rand = cfgd.get('mol_mix', 10) + 1
+            g['rnd'] = np.random.RandomState(22).uniform(1e-5, 1 - 1e-5, [Tn, B, n_rand]).astype(np.float32)
+            g['forced'] = np.random.RandomState(23).uniform(-1, 1, [B, Tn]).astype(np.float32)
+            teacher_case(R, g, out, tag, tmp, w)
+        else:
+            student_case(R, g, out, tag, tmp, w)
+        for k, v in g.items():
+            out['{}/in_{}'.format(tag, k)] = v
+
+
+def main():
+    R = import_reference()
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag in ('iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'):
+            student_case(R, np.load(os.path.join(HERE, tag + '.npz')), out, tag, tmp)
+        for tag in ('ar_mol', 'ar_ce_mulaw', 'ar_gauss'):
+            teacher_case(R, np.load(os.path.join(HERE, tag + '.npz')), out, tag, tmp)
+        extra_cases(R, out, tmp)
+    out['numpy_version'] = np.array(np.__version__)
+    np.savez_compressed(OUT, **out)
+    print('wrote', OUT, os.path.getsize(OUT), 'bytes,', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,229 @@
+"""The float path against vectors produced by the REFERENCE'S OWN Python (tests/golden/ref_float.npz).
+
+tests/golden/make_ref_float.py imports the reference's wavenet/*.py and auxilaries/utils.py unmodified and drives them the way
+eval_parallel_wavenet.py / eval_wavenet.py do (parallelgen.synthesis, fastgen.load_deconv_stack / load_fastgen / synthesis,
+Wavenet.feed_forward, Fastgen.cond_vars), with `import tensorflow` resolved to a numpy evaluator of the TensorFlow primitives
+those files call (tests/golden/tf_standin.py; TensorFlow itself is not installed).  What that pins: every decision the
+reference's code makes (names, scopes, checkpoint keys, dilation / crop / tap / gate arithmetic, flow recursion, queue
+discipline, samplers, quantiser, driver loops).  What it does not: TensorFlow's kernels (restated from their documented
+semantics) and TF's random generators (injected).  `*_f64` = tf.float32 evaluated in float64, `*_f32` = in float32.
+
+CPU tests hold the oracle (oracle/wavenet_np.py) and the older oracle-made goldens to these vectors; the `gpu` tests hold the
+HIP engine, through the C ABI, to them directly.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+STUDENT_GOLD = ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw']
+STUDENT_EXTRA = ['iaf_wn_resize', 'iaf_teacher_deconv']
+TEACHER_GOLD = ['ar_mol', 'ar_ce_mulaw', 'ar_gauss']
+TEACHER_EXTRA = ['ar_wn_resize']
+
+
+@pytest.fixture(scope='module')
+def R():
+    return np.load(os.path.join(GOLD, 'ref_float.npz'))
+
+
+def _case(R, tag):
+    """(inputs dict, config dict, weights) of a case: make_golden's inputs for its tags, the fixture's own otherwise."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    if tag + '/in_cfg_json' in R.files:
+        g = {k[len(tag) + 4:]: R[k] for k in R.files if k.startswith(tag + '/in_')}
+        cfgd = json.loads(str(g['cfg_json']))
+        w = wts.synthetic_weights(cfg.load_hparams(cfgd), seed=int(g['seed']), init=str(g['init']))
+    else:
+        g = np.load(os.path.join(GOLD, tag + '.npz'))
+        cfgd = json.loads(str(g['cfg_json']))
+        w = O.synth_weights(O.HP(cfgd), str(R[tag + '/kind']), seed=int(g['seed']), init=str(g['init']))
+    return g, cfgd, w
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU: the oracle, the product's naming and the older goldens against the reference's code
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', STUDENT_GOLD + STUDENT_EXTRA)
+def test_oracle_student_equals_the_reference_code(R, tag):
+    """parallel_wavenet.py:200-345 + parallelgen.py:11-19 executed, against oracle.iaf_feed_forward on the noise the
+    reference graph drew: float64 to rounding (1e-12 of the range), float32 within what two float32 evaluation orders
+    differ by; upsampler output (masked.py:235-322) likewise; quantised audio equal except one step at a boundary."""
+    from oracle import wavenet_np as O
+    g, cfgd, w = _case(R, tag)
+    hp = O.HP(cfgd)
+    share = hp.get('use_share_deconv', False) or hp.get('use_teacher_deconv', False)
+    Q = O.quant_chann_of(hp)
+    for fl, dt, tol in (('f64', np.float64, 1e-12), ('f32', np.float32, 5e-6)):
+        ri = R['{}/rand_input_{}'.format(tag, fl)]
+        ff = O.iaf_feed_forward(g['mel'], ri, w, hp, dt)
+        rng = max(1.0, float(np.abs(R[tag + '/x_f64']).max()))
+        for k in ('x', 'mean_tot', 'scale_tot', 'log_scale_tot'):
+            ref = R['{}/{}_{}'.format(tag, k, fl)]
+            assert ff[k].shape == ref.shape
+            assert np.abs(ff[k] - ref).max() <= tol * rng, (tag, fl, k)
+        enc = O.deconv_stack(g['mel'], w, hp, 'iaf_share' if share else 'iaf_1', dt)
+        assert np.abs(enc[:, ::7, ::5] - R['{}/enc_sub_{}'.format(tag, fl)]).max() <= tol * max(1.0, np.abs(enc).max())
+        wav, _ = O.clip_quant_scale(ff['x'], Q, hp.use_mu_law, dt)
+        d = np.abs(wav.astype(np.float64) - R['{}/wav_{}'.format(tag, fl)])
+        if fl == 'f64':
+            assert d.max() <= 2.0 ** -23                         # the fixture stores the audio as float32
+        else:
+            assert (d > 2.0 ** -23).mean() <= 0.05 and d.max() <= (2.5 / Q if not hp.use_mu_law else 0.05)
+    # the reference's own identity (tests/test_parallel_wavenet.py:62-64): x == rand_input * scale_tot + mean_tot
+    assert np.array_equal(R[tag + '/x_f64'], R[tag + '/rand_input_f64'] * R[tag + '/scale_tot_f64'] + R[tag + '/mean_tot_f64'])
+
+
+@pytest.mark.parametrize('tag', TEACHER_GOLD + TEACHER_EXTRA)
+def test_oracle_teacher_equals_the_reference_code(R, tag):
+    """fastgen.py:58-88 (encoding), wavenet.py:157-291 (full-sequence teacher on a forced waveform), wavenet.py:353-377
+    (cond_vars), wavenet.py:379-514 + masked.py:328-405 + loss_func.py:140-206 + fastgen.py:128-169 (the incremental
+    sampler's loop with its queues), executed, against the oracle: float64 to rounding, index streams identical."""
+    from oracle import wavenet_np as O
+    g, cfgd, w = _case(R, tag)
+    hp = O.HP(cfgd)
+    for fl, dt, tol in (('f64', np.float64, 1e-12), ('f32', np.float32, 5e-6)):
+        enc_r = R['{}/enc_{}'.format(tag, fl)]
+        enc = O.deconv_stack(g['mel'], w, hp, '', dt)
+        assert np.abs(enc - enc_r).max() <= tol * max(1.0, np.abs(enc_r).max())
+        ref = R['{}/out_forced_{}'.format(tag, fl)]
+        out = O.teacher_feed_forward(O.encode_signal(g['forced'], hp, dt), enc_r, w, hp, dt)
+        assert np.abs(out - ref).max() <= tol * max(1.0, np.abs(ref).max())
+        wav, idx, outs = O.fastgen_synthesis(enc_r.astype(np.float32), g['rnd'], w, hp, dt, return_out=True)
+        assert np.array_equal(idx, R['{}/free_idx_{}'.format(tag, fl)])
+        assert np.abs(wav - R['{}/free_wav_{}'.format(tag, fl)]).max() <= 2.0 ** -23
+        fo = R['{}/free_out_{}'.format(tag, fl)]
+        assert np.abs(outs - fo).max() <= tol * max(1.0, np.abs(fo).max())
+        names = sorted(['mel_cond_%d' % (i + 1) for i in range(hp.num_layers)])
+        cond = np.stack([O._conv(enc_r, w, n, hp, dtype=dt)[:, ::5, ::7] for n in names])
+        assert np.abs(cond - R['{}/cond_sub_{}'.format(tag, fl)]).max() <= tol * max(1.0, np.abs(cond).max())
+        c1 = O._conv(enc_r, w, 'mel_cond_out1', hp, dtype=dt)[:, ::5, ::7]
+        assert np.abs(c1 - R['{}/cond_out1_sub_{}'.format(tag, fl)]).max() <= tol * max(1.0, np.abs(c1).max())
+        # K1 on the reference itself: its incremental graph, teacher-forced, IS its full-sequence graph
+        assert float(R['{}/k1_{}'.format(tag, fl)]) <= (1e-12 if fl == 'f64' else 5e-6)
+
+
+@pytest.mark.parametrize('tag', STUDENT_GOLD + STUDENT_EXTRA + TEACHER_GOLD + TEACHER_EXTRA)
+def test_variable_and_checkpoint_names_are_the_reference_graphs(R, tag):
+    """The variables the reference's graph CREATES (name, shape) and the checkpoint keys its Saver ASKS for
+    (fastgen.py:12-14, parallelgen.py:6-8,29-41) are what weights.expected_variables / checkpoint_keys say -- rows a13,
+    a14.  (The checkpoint those graphs were restored from was written by weights.save_checkpoint.)"""
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    _, cfgd, w = _case(R, tag)
+    hp = cfg.load_hparams(cfgd)
+    ref_vars = sorted((n, tuple(s)) for n, s in json.loads(str(R[tag + '/vars'])))
+    mine = sorted((n, tuple(int(v) for v in s)) for n, s in wts.expected_variables(hp))
+    assert mine == ref_vars
+    assert sorted(w.keys()) == [n for n, _ in ref_vars]
+    assert sorted(wts.checkpoint_keys(w, hp).values()) == sorted(json.loads(str(R[tag + '/ckpt_keys'])))
+    if tag == 'iaf_teacher_deconv':
+        keys = json.loads(str(R[tag + '/ckpt_keys']))
+        assert 'iaf_share/trans_conv_1/kernel' in keys and 'iaf_1/start_conv/W/ExponentialMovingAverage' in keys
+    if str(R[tag + '/kind']) == 'teacher':          # the incremental graph takes the encoding: no upsampler variables
+        fg = set(json.loads(str(R[tag + '/ckpt_keys_fastgen'])))
+        assert fg == {k for k in wts.checkpoint_keys(w, hp).values() if 'trans_conv' not in k and 'resize_conv' not in k}
+
+
+@pytest.mark.parametrize('tag', STUDENT_GOLD + TEACHER_GOLD)
+def test_the_oracle_made_goldens_agree_with_the_reference_code(R, tag):
+    """tests/golden/<tag>.npz (oracle-made, what the other GPU tests compare with) against the reference-made vectors of the
+    same case.  Teacher: same inputs, equal to rounding.  Student: the golden's noise is the float32 rounding of the noise
+    the reference graph computes in float64, so the outputs differ by that rounding carried through the flows."""
+    g = np.load(os.path.join(GOLD, tag + '.npz'))
+    if tag in TEACHER_GOLD:
+        ref = R[tag + '/out_forced_f64']
+        assert np.abs(g['out_forced'] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.abs(g['enc'] - R[tag + '/enc_f64']).max() <= 2e-7 * max(1.0, np.abs(g['enc']).max())
+        assert np.array_equal(g['free_idx'], R[tag + '/free_idx_f32'])
+        assert np.array_equal(g['free_idx'], R[tag + '/free_idx_f64'])
+    else:
+        rng = max(1.0, float(np.abs(g['x']).max()))
+        assert np.abs(g['noise'] - R[tag + '/rand_input_f64']).max() <= 1e-6 * max(1.0, np.abs(g['noise']).max())
+        for k in ('x', 'mean_tot', 'scale_tot'):
+            assert np.abs(g[k] - R['{}/{}_f64'.format(tag, k)]).max() <= 2e-6 * rng
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP engine through the C ABI against the reference-made vectors
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused', 'f32'])
+@pytest.mark.parametrize('tag', STUDENT_GOLD + STUDENT_EXTRA)
+def test_engine_student_against_the_reference_code(R, tag, precision):
+    """wn_iaf_generate on the noise the reference graph drew, against what the reference's code computed from it:
+    2e-5 of the range on x / mean_tot / scale_tot (north_star: 1e-3), audio within one quantiser step and only at a
+    boundary of the reference's pre-quantisation value."""
+    from nsynth_wavenet_amd.engine import Engine
+    g, cfgd, w = _case(R, tag)
+    eng = Engine(cfgd, precision=precision).load_weights(w)
+    noise = R[tag + '/rand_input_f64'].astype(np.float32)
+    out = eng.iaf_generate(g['mel'], noise, want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot'))
+    x_ref = R[tag + '/x_f64']
+    rng = max(1.0, float(np.abs(x_ref).max()))
+    for k in ('x', 'mean_tot', 'scale_tot'):
+        ref = R['{}/{}_f64'.format(tag, k)]
+        err = float(np.abs(_np(out[k]) - ref).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(ref).max()), rng if k == 'x' else 0.0), (tag, precision, k, err)
+    Q = 256 if cfgd['use_mu_law'] else 65536
+    y = np.clip(x_ref, -1, 1 - 2.0 / Q) * (Q / 2)
+    idx_ref = np.floor(y).astype(np.int64)
+    di = np.abs(_np(out['idx']).astype(np.int64) - idx_ref)
+    dx = np.abs(np.clip(_np(out['x']).astype(np.float64), -1, 1 - 2.0 / Q) - np.clip(x_ref, -1, 1 - 2.0 / Q)) * (Q / 2)
+    assert np.all(di <= np.ceil(dx) + (dx > 0))
+    flips = di != 0
+    margin = np.minimum(y - np.floor(y), np.floor(y) + 1 - y)
+    assert np.all(margin[flips] <= dx[flips] + 1e-9)
+    assert np.abs(_np(out['wav']) - R[tag + '/wav_f64']).max() <= 1e-3
+    print('{} {}: max|x - reference code| = {:.2e} on a range of {:.2f}; {} of {} indices one step off, all at a boundary'.format(
+        tag, precision, float(np.abs(_np(out['x']) - x_ref).max()), rng, int(flips.sum()), di.size))
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', TEACHER_GOLD + TEACHER_EXTRA)
+def test_engine_teacher_against_the_reference_code(R, tag):
+    """wn_deconv, the teacher-forced AR steps (== the reference's full-sequence teacher) and the free-running loop with the
+    sampler's randoms injected, against what the reference's code computed."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g, cfgd, w = _case(R, tag)
+    hp = O.HP(cfgd)
+    eng = Engine(cfgd).load_weights(w)
+    enc_r = R[tag + '/enc_f64']
+    enc = _np(eng.deconv(g['mel']))
+    assert enc.shape == enc_r.shape and np.abs(enc - enc_r).max() <= 1e-5 * max(1.0, np.abs(enc_r).max())
+    enc32 = enc_r.astype(np.float32)
+    ref = R[tag + '/out_forced_f64']
+    out = eng.ar_generate(enc32, g['rnd'], forced_wav=g['forced'], want_out=True)
+    assert np.abs(_np(out['out_params']) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    out = eng.ar_generate(enc32, g['rnd'], want_out=True)
+    gi, gop = _np(out['idx']), _np(out['out_params'])
+    ri = R[tag + '/free_idx_f64']
+    diff = gi != ri
+    Tn = gi.shape[1]
+    first = int(np.argwhere(diff)[:, 1].min()) if diff.any() else Tn
+    Q = 256 if cfgd['use_mu_law'] else 65536
+    if first < Tn:                                  # the two loops may fork only where the engine's own pre-floor value
+        assert not diff[:, :first].any()            # sits at a decision boundary (then by one step)
+        rows = np.where(diff[:, first])[0]
+        _, margin, gap = O.sample_margin(gop[:, first], g['rnd'][first], hp)
+        lim = 2e-4 if hp.loss_type == 'ce' else (0.25 if Q == 65536 else 5e-3)
+        near = margin[rows] <= lim
+        if hp.loss_type == 'mol':
+            near |= gap[rows] <= 1e-4
+        assert np.all(near), (first, margin[rows])
+    else:
+        assert np.abs(_np(out['wav']) - R[tag + '/free_wav_f64']).max() <= 2.0 ** -23
+    fo = R[tag + '/free_out_f64'][:, :max(first, 1)]
+    assert np.abs(gop[:, :max(first, 1)] - fo).max() <= 2e-5 * max(1.0, np.abs(fo).max())
+    print('{}: free run identical to the reference code\'s loop for {} of {} steps'.format(tag, first, Tn))
+    eng.close()
