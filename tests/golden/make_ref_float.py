@@ -3,7 +3,7 @@ for the TensorFlow primitives (tests/golden/tf_standin.py -- read its header for
 
 Run in the build container only (needs /root/reference; nothing of it travels -- only the .npz below):
     python tests/golden/make_ref_float.py
-Writes tests/golden/ref_float.npz.
+Writes tests/golden/ref_float.npz;  `--full` writes tests/golden/ref_float_full.npz (BASELINE configs[1] at full size) instead.
 
 For every case of tests/golden/make_golden.py (same configs, same mel / random seeds, same synthetic weights) the
 reference's files are imported unmodified from /root/reference and DRIVEN THE WAY THE REFERENCE DRIVES THEM:
@@ -115,7 +115,7 @@ def find_bias_add(root, bias_name):
     raise KeyError(bias_name)
 
 
-def student_case(R, g, out, tag, tmp, w=None):
+def student_case(R, g, out, tag, tmp, w=None, floats=(('f64', np.float64), ('f32', np.float32))):
     cfgd = json.loads(str(g['cfg_json']))
     hp_o = O.HP(cfgd)
     if w is None:
@@ -128,7 +128,7 @@ def student_case(R, g, out, tag, tmp, w=None):
     gauss = cfgd['loss_type'] == 'gauss'
     draw = rs.standard_normal([B, T]) if gauss else rs.uniform(1e-5, 1 - 1e-5, [B, T])
     draw = draw.astype(np.float32).astype(np.float64)          # float32-valued, so both arithmetics see the same numbers
-    for fl, dt in (('f64', np.float64), ('f32', np.float32)):
+    for fl, dt in floats:
         tf.set_float(dt)
         tf.Saver.requested = []
         hparams = reference_hparams(cfgd, 'student')
@@ -312,8 +312,35 @@ def extra_cases(R, out, tmp):
             out['{}/in_{}'.format(tag, k)] = v
 
 
+def full_size_case(R, tmp):
+    """BASELINE.json configs[1] at its full size -- parallel_wavenet.json as shipped, one utterance of 384 frames = 76 800
+    samples, bench.py's weights (synthetic_weights(seed=1234, init='tf')) -- through parallelgen.synthesis as written, float64.
+    Own file (ref_float_full.npz): noise and x in float64, the rest as float32."""
+    cfgd = repo_cfg('parallel_wavenet.json')
+    hp = cfgmod.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=1234, init='tf')
+    g = {'cfg_json': np.array(json.dumps(cfgd)), 'seed': np.array(1234), 'init': np.array('tf'),
+         'mel': np.random.RandomState(31).uniform(0, 1, [1, 384, 80]).astype(np.float32)}
+    out = {}
+    student_case(R, g, out, 'full', tmp, w, floats=(('f64', np.float64),))
+    keep = {'full/rand_input_f64': np.float64, 'full/x_f64': np.float64, 'full/mean_tot_f64': np.float32,
+            'full/scale_tot_f64': np.float32, 'full/wav_f64': np.float32}
+    res = {k: out[k].astype(dt) for k, dt in keep.items()}
+    res['full/enc_sub_f64'] = out['full/enc_sub_f64'][:, ::16].astype(np.float32)
+    for k, v in g.items():
+        res['full/in_' + k] = v
+    res['full/kind'] = np.array('student')
+    p = os.path.join(HERE, 'ref_float_full.npz')
+    np.savez_compressed(p, **res)
+    print('wrote', p, os.path.getsize(p), 'bytes')
+
+
 def main():
     R = import_reference()
+    if '--full' in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            full_size_case(R, tmp)
+        return
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for tag in ('iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'):

@@ -227,3 +227,53 @@ def test_engine_teacher_against_the_reference_code(R, tag):
     assert np.abs(gop[:, :max(first, 1)] - fo).max() <= 2e-5 * max(1.0, np.abs(fo).max())
     print('{}: free run identical to the reference code\'s loop for {} of {} steps'.format(tag, first, Tn))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] at its full size (one utterance of 384 frames = 76 800 samples, bench.py's weights), through
+# parallelgen.synthesis as written: tests/golden/ref_float_full.npz (make_ref_float.py --full)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def RF():
+    return np.load(os.path.join(GOLD, 'ref_float_full.npz'))
+
+
+def test_oracle_equals_the_reference_code_at_full_size(RF):
+    from oracle import wavenet_np as O
+    g, cfgd, w = _case(RF, 'full')
+    hp = O.HP(cfgd)
+    ff = O.iaf_feed_forward(g['mel'], RF['full/rand_input_f64'], w, hp, np.float64)
+    assert ff['x'].shape == (1, 76800)
+    assert np.abs(ff['x'] - RF['full/x_f64']).max() <= 1e-12
+    assert np.abs(ff['mean_tot'] - RF['full/mean_tot_f64']).max() <= 1e-6          # stored as float32
+    assert np.abs(ff['scale_tot'] - RF['full/scale_tot_f64']).max() <= 1e-6
+    wav, _ = O.clip_quant_scale(ff['x'], 65536, False, np.float64)
+    assert np.array_equal(wav.astype(np.float32), RF['full/wav_f64'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('groups', [1, -1])
+def test_engine_equals_the_reference_code_at_full_size(RF, groups):
+    """The headline configuration on the default arithmetic, layer groups in LDS (what bench.py times) and per-layer
+    launches, against the reference's code: 2e-5 (north_star: 1e-3), indices one step off only at a boundary."""
+    from nsynth_wavenet_amd.engine import Engine
+    g, cfgd, w = _case(RF, 'full')
+    eng = Engine(cfgd).load_weights(w)
+    eng.set_layer_groups(groups)
+    assert eng.iaf_layer_groups(1, 384) is (groups > 0)
+    out = eng.iaf_generate(g['mel'], RF['full/rand_input_f64'].astype(np.float32), want=('wav', 'idx', 'x', 'mean_tot', 'scale_tot'))
+    x_ref = RF['full/x_f64']
+    err = float(np.abs(_np(out['x']) - x_ref).max())
+    assert err <= 2e-5 * max(1.0, float(np.abs(x_ref).max()))
+    assert np.abs(_np(out['mean_tot']) - RF['full/mean_tot_f64']).max() <= 2e-5
+    assert np.abs(_np(out['scale_tot']) - RF['full/scale_tot_f64']).max() <= 2e-5
+    y = np.clip(x_ref, -1, 1 - 2.0 / 65536) * 32768
+    di = np.abs(_np(out['idx']).astype(np.int64) - np.floor(y).astype(np.int64))
+    dx = np.abs(np.clip(_np(out['x']).astype(np.float64), -1, 1 - 2.0 / 65536) * 32768 - y)
+    flips = di != 0
+    assert di.max() <= 1 and flips.mean() < 0.02
+    assert np.all(np.minimum(y - np.floor(y), np.floor(y) + 1 - y)[flips] <= dx[flips] + 1e-9)
+    assert np.abs(_np(out['wav']) - RF['full/wav_f64']).max() <= 2.0 ** -15 + 1e-9
+    print('full size, groups {:+d}: max|x - reference code| = {:.2e}; {} of {} indices one step off, all at a boundary'.format(
+        groups, err, int(flips.sum()), di.size))
+    eng.close()
