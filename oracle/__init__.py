@@ -16,8 +16,9 @@ is NO TENSORFLOW-PRODUCED VECTOR.  What exists instead, strongest first:
      calculate_cond_vars; Wavenet.encode_signal + feed_forward), with `import tensorflow` resolved to
      tests/golden/tf_standin.py: a numpy evaluator of the ~70 TensorFlow primitives those files call (graph, session,
      placeholders, variable scopes, Saver.restore, conv2d, conv2d_transpose, pad / slice / reshape / transpose,
-     FIFOQueue, random_uniform, ...).  Eleven cases (the seven of make_golden.py plus weight-norm + resize-conv student
-     and teacher, and a use_teacher_deconv student), each in float64 and float32.  This oracle agrees with those runs to
+     FIFOQueue, random_uniform, ...).  Eleven small cases (the seven of make_golden.py plus weight-norm + resize-conv student
+     and teacher, and a use_teacher_deconv student), each in float64 and float32, plus BASELINE configs[1] at its full size
+     (one 76 800-sample utterance through parallelgen.synthesis) and wavenet_mol.json as shipped for 400 incremental steps.  This oracle agrees with those runs to
      float64 rounding (<= 1e-12 of the range) on x / mean_tot / scale_tot / log_scale_tot, the upsampler output, the
      full-sequence teacher, cond_vars and every network output of the free-running incremental loop; the sampled index
      streams are IDENTICAL; the variables the reference graphs create and the checkpoint keys their Savers request are

@@ -312,6 +312,54 @@ def extra_cases(R, out, tmp):
             out['{}/in_{}'.format(tag, k)] = v
 
 
+def teacher_full_width_case(R, out, tmp):
+    """BASELINE.json configs[0] / [3]: wavenet_mol.json AS SHIPPED (width 512, 30 layers, MoL-10) through the reference's
+    incremental graph (load_fastgen + the loop of fastgen.synthesis, and synthesis() itself), teacher-forced and free
+    running, float64, 400 steps on a seeded encoding (the upsampler at these widths is the students' iaf_share case)."""
+    from scipy.io import wavfile
+    tag = 'ar_mol_full'
+    cfgd = repo_cfg('wavenet_mol.json')
+    hp = cfgmod.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=1234, init='unit')
+    ckpt = wts.save_checkpoint(os.path.join(tmp, tag + '.npz'), w, hp)
+    B, Tn, M = 2, 400, cfgd['mol_mix']
+    rs = np.random.RandomState(41)
+    enc32 = (rs.standard_normal([B, Tn, cfgd['deconv_width']]) * 0.3).astype(np.float32)
+    rnd = rs.uniform(1e-5, 1 - 1e-5, [Tn, B, M + 1]).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    table = {0: lambda t: rnd[t][:, :M].reshape(B, 1, M), 1: lambda t: rnd[t][:, M].reshape(B, 1)}
+    tf.set_float(np.float64)
+    hparams = reference_hparams(cfgd, 'teacher')
+    tf.set_random_source(TableSource(table))
+    paths = [os.path.join(tmp, '{}_{}.wav'.format(tag, b)) for b in range(B)]
+    R.fastgen.synthesis(hparams, enc32, paths, ckpt)
+    wav_files = np.stack([wavfile.read(p)[1] for p in paths])
+    res = {}
+    for mode in ('free', 'forced'):
+        tf.set_random_source(TableSource(table))
+        with tf.Graph().as_default(), tf.Session() as sess:
+            fg = R.fastgen.load_fastgen(hparams, B)
+            out_node = find_bias_add(fg['sample'], 'out2/biases')
+            tf.train.Saver(R.fastgen.get_ema_shadow_dict(tf.trainable_variables())).restore(sess, ckpt)
+            sess.run(fg['init_ops'])
+            audio = np.zeros([B, 1])
+            idx, outs = np.zeros([B, Tn], np.int32), []
+            for t in range(Tn):
+                q, o, _ = sess.run([fg['sample'], out_node, fg['push_ops']],
+                                   feed_dict={fg['wav_in']: audio, fg['encoding_in']: enc32[:, t, :]})
+                audio = R.utils.inv_cast_quantize_numpy(q, 65536) if mode == 'free' else forced[:, t:t + 1]
+                idx[:, t] = q[:, 0]
+                outs.append(o)
+        res[mode] = (idx, np.stack(outs, axis=1))
+    assert np.array_equal(res['free'][0] / 32768.0, wav_files.astype(np.float64)), 'synthesis() wav != the re-run loop'
+    out[tag + '/free_idx_f64'] = res['free'][0]
+    out[tag + '/free_out_f64'] = res['free'][1].astype(np.float32)
+    out[tag + '/out_forced_f64'] = res['forced'][1]
+    out[tag + '/in_cfg_json'] = np.array(json.dumps(cfgd))
+    out[tag + '/kind'] = np.array('teacher')
+    print(tag, 'Tn', Tn, 'out range', float(np.abs(res['forced'][1]).max()))
+
+
 def full_size_case(R, tmp):
     """BASELINE.json configs[1] at its full size -- parallel_wavenet.json as shipped, one utterance of 384 frames = 76 800
     samples, bench.py's weights (synthetic_weights(seed=1234, init='tf')) -- through parallelgen.synthesis as written, float64.
@@ -353,6 +401,7 @@ def main():
         for tag in ('ar_mol', 'ar_ce_mulaw', 'ar_gauss'):
             teacher_case(R, np.load(os.path.join(HERE, tag + '.npz')), out, tag, tmp)
         extra_cases(R, out, tmp)
+        teacher_full_width_case(R, out, tmp)
     out['numpy_version'] = np.array(np.__version__)
     # the float32-arithmetic twins are kept for the principal outputs only
     for k in [k for k in out if k.endswith('_f32') and k.split('/')[1].rsplit('_', 1)[0] not in

@@ -286,3 +286,73 @@ def test_engine_equals_the_reference_code_at_full_size(RF, groups):
     print('full size, groups {:+d}: max|x - reference code| = {:.2e}; {} of {} indices one step off, all at a boundary'.format(
         groups, err, int(flips.sum()), di.size))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] / [3]: wavenet_mol.json as shipped (width 512, 30 layers, MoL-10), 400 steps of the reference's
+# incremental graph, teacher-forced and free running (make_ref_float.py: teacher_full_width_case)
+# ------------------------------------------------------------------------------------------------------------------
+def _teacher_full_inputs():
+    rs = np.random.RandomState(41)
+    B, Tn, M = 2, 400, 10
+    enc32 = (rs.standard_normal([B, Tn, 256]) * 0.3).astype(np.float32)
+    rnd = rs.uniform(1e-5, 1 - 1e-5, [Tn, B, M + 1]).astype(np.float32)
+    forced = rs.uniform(-1, 1, [B, Tn]).astype(np.float32)
+    return enc32, rnd, forced
+
+
+def test_oracle_full_width_teacher_equals_the_reference_code(R):
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    cfgd = json.loads(str(R['ar_mol_full/in_cfg_json']))
+    assert cfgd == load_json('wavenet_mol.json')
+    hp = O.HP(cfgd)
+    w = wts.synthetic_weights(cfg.load_hparams(cfgd), seed=1234, init='unit')
+    enc32, rnd, forced = _teacher_full_inputs()
+    wav, idx, outs = O.fastgen_synthesis(enc32, rnd, w, hp, np.float64, return_out=True)
+    assert np.array_equal(idx, R['ar_mol_full/free_idx_f64'])
+    assert np.abs(outs - R['ar_mol_full/free_out_f64']).max() <= 1e-5           # stored as float32
+    fg = O.Fastgen(w, hp, 2, np.float64)
+    prev = np.zeros([2, 1])
+    ref = R['ar_mol_full/out_forced_f64']
+    for t in range(forced.shape[1]):
+        o = fg.out_params(prev, enc32[:, t])
+        assert np.abs(o - ref[:, t]).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        prev = forced[:, t:t + 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['gemv', 'mfma'])
+def test_engine_full_width_teacher_against_the_reference_code(R, mode, monkeypatch):
+    """wavenet_mol.json as shipped on the tuned AR step kernels (GEMV step, and the batched MFMA step forced onto the same
+    two utterances): every teacher-forced network output of 400 steps against the reference's incremental graph, and the
+    free-running loop identical to the reference's until a step whose pre-floor value sits at a decision boundary."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    monkeypatch.setenv('WN_AR_MODE', mode)
+    cfgd = load_json('wavenet_mol.json')
+    hp = O.HP(cfgd)
+    w = wts.synthetic_weights(cfg.load_hparams(cfgd), seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    enc32, rnd, forced = _teacher_full_inputs()
+    ref = R['ar_mol_full/out_forced_f64']
+    out = eng.ar_generate(enc32, rnd, forced_wav=forced, want_out=True)
+    err = float(np.abs(_np(out['out_params']) - ref).max())
+    assert err <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    out = eng.ar_generate(enc32, rnd, want_out=True)
+    gi, gop = _np(out['idx']), _np(out['out_params'])
+    ri = R['ar_mol_full/free_idx_f64']
+    diff = gi != ri
+    Tn = gi.shape[1]
+    first = int(np.argwhere(diff)[:, 1].min()) if diff.any() else Tn
+    if first < Tn:
+        assert not diff[:, :first].any()
+        rows = np.where(diff[:, first])[0]
+        _, margin, gap = O.sample_margin(gop[:, first], rnd[first], hp)
+        assert np.all((margin[rows] <= 0.25) | (gap[rows] <= 1e-4)), (first, margin[rows], gap[rows])
+    fo = R['ar_mol_full/free_out_f64'][:, :max(first, 1)]
+    assert np.abs(gop[:, :max(first, 1)] - fo).max() <= 2e-5 * max(1.0, np.abs(fo).max())
+    print('wavenet_mol.json as shipped, {} step: max|out - reference code| = {:.2e} over 400 forced steps; free run identical '
+          'for {} of {} steps'.format(mode, err, first, Tn))
+    eng.close()
