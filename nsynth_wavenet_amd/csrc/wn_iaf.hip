@@ -41,10 +41,9 @@ __device__ inline float tanhf_(float a) { return 1.f - 2.f * __builtin_amdgcn_rc
 
 // ---------------- noise (parallel_wavenet.py:172-184) ----------------
 // 4 samples per thread.  logistic: log u - log(1-u), u ~ U(1e-5, 1-1e-5); gauss: Box-Muller.
-__global__ void iaf_noise_kernel(float* __restrict__ x0, float* __restrict__ x, int64_t T, int XR,
-                                 uint64_t seed, int gauss) {
-    const int b = blockIdx.y;
-    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline void iaf_noise_body(float* __restrict__ x0, float* __restrict__ x, int64_t T, int XR,
+                                      uint64_t seed, int gauss, int bx, int b) {
+    const int64_t i4 = (int64_t)bx * blockDim.x + threadIdx.x;
     if (i4 * 4 >= T) return;
     uint32_t c[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)b, 0x49414630u};
     wn_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -70,34 +69,71 @@ __global__ void iaf_noise_kernel(float* __restrict__ x0, float* __restrict__ x, 
     *reinterpret_cast<f4*>(x + (size_t)b * XR + IAF_XP + i4 * 4) = (f4){v[0], v[1], v[2], v[3]};
 }
 
-__global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __restrict__ x, int64_t T, int XR) {
-    const int b = blockIdx.y;
-    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void iaf_noise_kernel(float* __restrict__ x0, float* __restrict__ x, int64_t T, int XR,
+                                 uint64_t seed, int gauss) {
+    iaf_noise_body(x0, x, T, XR, seed, gauss, blockIdx.x, blockIdx.y);
+}
+
+__device__ inline void iaf_copy_noise_body(const float* __restrict__ noise, float* __restrict__ x, int64_t T, int XR,
+                                           int bx, int b) {
+    const int64_t i4 = (int64_t)bx * blockDim.x + threadIdx.x;
     if (i4 * 4 >= T) return;
     *reinterpret_cast<f4*>(x + (size_t)b * XR + IAF_XP + i4 * 4) =
         *reinterpret_cast<const f4*>(noise + (size_t)b * T + i4 * 4);
 }
 
+__global__ void iaf_copy_noise_kernel(const float* __restrict__ noise, float* __restrict__ x, int64_t T, int XR) {
+    iaf_copy_noise_body(noise, x, T, XR, blockIdx.x, blockIdx.y);
+}
+
 // zero the left pads of `rows` rows (row stride rs floats, pad floats each)
-// zero left pads of both activation buffers and of the flow input, one launch (blockIdx.z picks)
+// zero left pads of both activation buffers and of the flow input, one launch (bz picks)
 // dl_rj > 0: lB holds the DL layout of wn_iaf_g.hip (32 residue rows of dl_rj 16-byte words per group row, 64 zero
 // words in front of each) instead of one left pad per row
-__global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
-                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status,
-                                 int dl_rj) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.y == 0 && c == 0 && blockIdx.z == 0) *status = 0u;  // range-guard word of this call (wn_codec.h)
+__device__ inline void zero_pads_body(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
+                                      float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status,
+                                      int dl_rj, int bx, int by, int bz, int gy) {
+    const int c = bx * blockDim.x + threadIdx.x;
+    if (by == 0 && c == 0 && bz == 0) *status = 0u;  // range-guard word of this call (wn_codec.h)
     // grid.y is capped (65 535 rows per launch dimension): rows are walked
-    for (int row = blockIdx.y; row < max(rows, xrows); row += gridDim.y) {
-        if (blockIdx.z < 2) {
-            float* p = blockIdx.z ? lB : lA;
-            if (blockIdx.z == 1 && dl_rj > 0) {
+    for (int row = by; row < max(rows, xrows); row += gy) {
+        if (bz < 2) {
+            float* p = bz ? lB : lA;
+            if (bz == 1 && dl_rj > 0) {
                 // 32 x 64 words x 4 floats = pad floats again: float c -> residue c / 256, float c % 256 of its pad
                 if (row < rows && c < pad) p[(size_t)row * rs + (size_t)(c >> 8) * dl_rj * 4 + (c & 255)] = 0.f;
             } else if (row < rows && c < pad) p[(size_t)row * rs + c] = 0.f;
         } else if (row < xrows && c < xpad) {
             x[(size_t)row * xrs + c] = 0.f;
         }
+    }
+}
+
+__global__ void zero_pads_kernel(float* __restrict__ lA, float* __restrict__ lB, int64_t rs, int pad, int rows,
+                                 float* __restrict__ x, int64_t xrs, int xpad, int xrows, unsigned* __restrict__ status,
+                                 int dl_rj) {
+    zero_pads_body(lA, lB, rs, pad, rows, x, xrs, xpad, xrows, status, dl_rj, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+// The call's prologue as ONE launch (round 5): the zero pads and the flow input (noise drawn here, or the caller's copied)
+// are independent element-wise jobs of a few microseconds each; a 1-D grid holds the blocks of both, pads first.
+struct PrologueArgs {
+    float *lA, *lB, *x, *x0g;
+    const float* noise;
+    unsigned* status;
+    int64_t rs, xrs, T;
+    uint64_t seed;
+    int pad, rows, xpad, xrows, dl_rj, pgx, pgy, npad, ngx, XR, gauss;
+};
+__global__ void iaf_prologue_kernel(const PrologueArgs A) {
+    const int bid = blockIdx.x;
+    if (bid < A.npad) {
+        const int bx = bid % A.pgx, by = (bid / A.pgx) % A.pgy, bz = bid / (A.pgx * A.pgy);
+        zero_pads_body(A.lA, A.lB, A.rs, A.pad, A.rows, A.x, A.xrs, A.xpad, A.xrows, A.status, A.dl_rj, bx, by, bz, A.pgy);
+    } else {
+        const int nb = bid - A.npad, bx = nb % A.ngx, b = nb / A.ngx;
+        if (A.noise) iaf_copy_noise_body(A.noise, A.x, A.T, A.XR, bx, b);
+        else iaf_noise_body(A.x0g, A.x, A.T, A.XR, A.seed, A.gauss, bx, b);
     }
 }
 
@@ -713,27 +749,23 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         return WN_OK;
     };
     if (int rc = part(0)) return rc;
-    // zero left pads
+    // prologue: zero left pads + the flow input (drawn on the device, or the caller's noise), one launch
+    const float* x0 = noise ? noise : x0g;
     {
+        PrologueArgs A{};
         // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
-        const int rows = f16x3 ? B * 16 : B * IAF_W;
-        const int64_t rs = f16x3 ? 4 * L.RS : L.RS;
-        const int pad = f16x3 ? 4 * IAF_LP : IAF_LP;
-        dim3 g((pad + 255) / 256, std::min(std::max(rows, 2 * B), 32768), 3);
-        hipLaunchKernelGGL(zero_pads_kernel, g, dim3(256), 0, st, lA, lB, rs, pad, rows, x, (int64_t)L.XR, IAF_XP, 2 * B, status,
-                           use_groups ? 64 + (int)(L.T / 32) : 0);
-    }
-    // noise
-    const float* x0 = noise;
-    {
-        dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
-        if (noise) {
-            hipLaunchKernelGGL(iaf_copy_noise_kernel, g, dim3(256), 0, st, noise, x, L.T, L.XR);
-        } else {
-            hipLaunchKernelGGL(iaf_noise_kernel, g, dim3(256), 0, st, x0g, x, L.T, L.XR, seed,
-                               c.loss_type == WN_LOSS_GAUSS ? 1 : 0);
-            x0 = x0g;
-        }
+        A.rows = f16x3 ? B * 16 : B * IAF_W;
+        A.rs = f16x3 ? 4 * L.RS : L.RS;
+        A.pad = f16x3 ? 4 * IAF_LP : IAF_LP;
+        A.lA = lA; A.lB = lB; A.x = x; A.x0g = x0g; A.noise = noise; A.status = status;
+        A.xrs = (int64_t)L.XR; A.xpad = IAF_XP; A.xrows = 2 * B;
+        A.dl_rj = use_groups ? 64 + (int)(L.T / 32) : 0;
+        A.pgx = (A.pad + 255) / 256;
+        A.pgy = std::min(std::max(A.rows, 2 * B), 32768);
+        A.npad = A.pgx * A.pgy * 3;
+        A.T = L.T; A.XR = L.XR; A.seed = seed; A.gauss = c.loss_type == WN_LOSS_GAUSS ? 1 : 0;
+        A.ngx = (int)((L.T / 4 + 255) / 256);
+        hipLaunchKernelGGL(iaf_prologue_kernel, dim3((unsigned)(A.npad + A.ngx * B)), dim3(256), 0, st, A);
     }
     const bool hoist = L.form == WN_COND_HOISTED;
     auto blob_u = [&](size_t off) { return reinterpret_cast<const unsigned*>(h->d_blob + off); };
