@@ -294,6 +294,15 @@ size_t wn_teacher_workspace_bytes(const wn_handle* h, int B, int F, int64_t T);
 int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, int B, int F, int64_t T,
                        float* out_params, void* ws, size_t ws_bytes, void* stream);
 
+/* Teacher scoring, the per-sample term of `Wavenet.calculate_loss` (wavenet/wavenet.py:293-316): log-likelihood of the
+ * audio wav [B,T] under out_params [B,T,out_width] (what wn_teacher_forward wrote) -- loss_func.mol_log_probs
+ * (wavenet/loss_func.py:22-63), gauss_log_prob (:104-119) or the negated cross entropy of ce_loss (:128-133), by the
+ * handle's loss_type, on the targets `Wavenet.encode_signal` derives from the raw audio (wavenet.py:157-178: mu-law / 128
+ * and the class index when use_mu_law, the audio itself otherwise).  log_prob [B,T]; the reference's scalar loss is
+ * minus its mean.  Asynchronous on `stream`; no workspace. */
+int wn_teacher_log_prob(wn_handle* h, const float* out_params, const float* wav, int B, int64_t T, float* log_prob,
+                        void* stream);
+
 /* 1 when wn_iaf_generate(B, F) evaluates the per-layer conditioning 1x1s in one hoisted GEMM per
  * deconv stack (the default of the split-fp16 path: the layer kernels then stream 768 B/sample
  * instead of 1536 and the small-dilation layers run two per launch), 0 for cond_mode 1 (fused)

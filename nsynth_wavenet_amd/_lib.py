@@ -22,7 +22,7 @@ SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_ia
            'wn_iaf_workspace_bytes_form', 'wn_iaf_range_status', 'wn_iaf_range_reset',
            'wn_iaf_range_status_since_reset', 'wn_clip_quant',
            'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph', 'wn_ar_cond_vars', 'wn_ar_cond_vars_floats',
-           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_profile_parts_only', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
+           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_teacher_log_prob', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_profile_parts_only', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
 
 
 class WnConfig(ctypes.Structure):
@@ -94,6 +94,7 @@ def load():
     lib.wn_teacher_workspace_bytes.argtypes = [vp, i32, i32, i64]
     lib.wn_teacher_workspace_bytes.restype = sz
     lib.wn_teacher_forward.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, sz, vp]
+    lib.wn_teacher_log_prob.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     lib.wn_profile_begin.argtypes = [vp]
     lib.wn_profile_pause.argtypes = [vp, c.c_int]
     lib.wn_profile_end.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]

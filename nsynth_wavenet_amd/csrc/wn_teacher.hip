@@ -397,6 +397,74 @@ int wn_pack_teacher(wn_handle* h, std::vector<float>& blob) {
     return WN_OK;
 }
 
+namespace {
+// Teacher scoring: log-likelihood per sample of the (encoded) audio under the output parameters of Wavenet.feed_forward --
+// the per-sample term of Wavenet.calculate_loss (wavenet/wavenet.py:293-316): loss_func.mol_log_probs (loss_func.py:22-63),
+// gauss_log_prob (:66-75,104-119) and the cross entropy of ce_loss (:128-133), on the targets Wavenet.encode_signal derives
+// from the raw audio (wavenet.py:157-178).  One wave per sample; lane i owns mixture i / strides over the classes.
+// The discretised-logistic mass cdf(x + 1/Q) - cdf(x - 1/Q) is evaluated as sigma(a) sigma(-b) (1 - exp(-(a - b))) with
+// a - b = 2 inv_s / Q formed directly: the difference of two float32 sigmoids the reference's formula takes loses all but
+// two digits of it at Q = 65 536 (the float64 evaluation of the reference's formula is what the tests compare with).
+__device__ inline float tl_softplus(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
+__device__ inline float tl_sigmoid(float v) {
+    const float e = expf(-fabsf(v));
+    return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+__device__ inline float tl_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline float tl_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void tg_log_prob_kernel(const float* __restrict__ out, const float* __restrict__ wav,
+                                                          float* __restrict__ lp, long long n, int ow, int loss, int Q, int mu) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* o = out + (size_t)i * ow;
+    const float x = wav[i];
+    const float xt = mu ? wn_mu_law_scaled(x) : x;                 // real_targets (wavenet.py:165-174)
+    const float NEG = -__builtin_inff();
+    float res;
+    if (loss == WN_LOSS_MOL) {
+        const int M = ow / 3;
+        float v = NEG, lg = NEG;
+        if (lane < M) {
+            lg = o[lane];
+            const float mean = o[M + lane], ls = fmaxf(o[2 * M + lane], -7.0f);
+            const float inv = expf(-ls), c = xt - mean, iq = 1.0f / (float)Q;
+            const float plus = inv * (c + iq), mn = inv * (c - iq);
+            const float max_thres = ((float)(Q - 1) - 0.5f) / ((float)Q * 0.5f) - 1.0f, min_thres = 0.5f / ((float)Q * 0.5f) - 1.0f;
+            const float delta = tl_sigmoid(plus) * tl_sigmoid(-mn) * (-expm1f(-2.0f * inv * iq));
+            v = xt < min_thres ? plus - tl_softplus(plus) : (xt > max_thres ? -tl_softplus(mn) : logf(fmaxf(delta, 1e-12f)));
+        }
+        const float lmax = tl_wave_max(lg);
+        const float lse = lmax + logf(tl_wave_sum(lane < M ? expf(lg - lmax) : 0.f));
+        v = lane < M ? v + (lg - lse) : NEG;
+        const float vmax = tl_wave_max(v);
+        res = vmax + logf(tl_wave_sum(lane < M ? expf(v - vmax) : 0.f));
+    } else if (loss == WN_LOSS_GAUSS) {
+        const float ls = fmaxf(o[1], -7.0f), z = (xt - o[0]) * expf(-ls);
+        res = -0.5f * z * z - ls - 0.9189385332046727f;             // Normal(mean, exp(ls)).log_prob(x)
+    } else {
+        // cate_targets (wavenet.py:166-176): the quantised audio shifted to [0, Q)
+        int label = (mu ? (int)floorf(wn_mu_law_scaled(x) * 128.0f) : (int)floorf(x * (float)Q * 0.5f)) + Q / 2;
+        label = min(max(label, 0), Q - 1);
+        float m = NEG;
+        for (int k = lane; k < ow; k += 64) m = fmaxf(m, o[k]);
+        m = tl_wave_max(m);
+        float sum = 0.f;
+        for (int k = lane; k < ow; k += 64) sum += expf(o[k] - m);
+        res = o[label] - (m + logf(tl_wave_sum(sum)));
+    }
+    if (lane == 0) lp[i] = res;
+}
+}  // namespace
+
 size_t wn_teacher_ws_bytes(const wn_handle* h, int B, int F, long long T) { return t_layout(h, B, F, T).total; }
 
 extern "C" size_t wn_teacher_workspace_bytes(const wn_handle* h, int B, int F, int64_t T) {
@@ -505,6 +573,23 @@ extern "C" int wn_teacher_forward(wn_handle* h, const float* wav, const float* m
         a.otm = out_params; a.ow = c.out_width;
         tg_launch<TG_EPI_OUT>(a, P.out2.mtiles, B, L.Tp, st);
     }
+    WN_HIP(h, hipGetLastError());
+    return WN_OK;
+}
+
+extern "C" int wn_teacher_log_prob(wn_handle* h, const float* out_params, const float* wav, int B, int64_t T, float* log_prob,
+                                   void* stream) {
+    if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_teacher_log_prob: null handle");
+    const wn_config& c = h->cfg;
+    if (c.kind != WN_KIND_TEACHER) return wn_fail(h, WN_EINVAL, "wn_teacher_log_prob: handle is not a Wavenet teacher");
+    if (B < 1 || T < 1 || !out_params || !wav || !log_prob) return wn_fail(h, WN_EINVAL, "wn_teacher_log_prob: bad argument");
+    const int Q = c.use_mu_law ? 256 : 65536;
+    if (c.loss_type == WN_LOSS_CE && c.out_width != Q)
+        return wn_fail(h, WN_EINVAL, "wn_teacher_log_prob: %d logits for %d classes", c.out_width, Q);
+    const long long n = (long long)B * T;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tg_log_prob_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, out_params, wav, log_prob,
+                       n, c.out_width, c.loss_type, Q, c.use_mu_law);
     WN_HIP(h, hipGetLastError());
     return WN_OK;
 }

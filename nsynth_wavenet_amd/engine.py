@@ -227,6 +227,19 @@ class Engine(object):
                                                     ws.numel(), self._stream()))
         return out
 
+    def teacher_log_prob(self, out_params, wav):
+        """Per-sample log-likelihood of wav [B,T] under out_params [B,T,out_width] (loss_func.py:22-63,104-119,128-133 on the
+        targets of Wavenet.encode_signal, wavenet.py:157-178) -> [B,T]; Wavenet.calculate_loss's 'loss' is minus its mean."""
+        out_params, wav = self._dev(out_params), self._dev(wav)
+        if wav.dim() != 2 or out_params.dim() != 3 or tuple(out_params.shape[:2]) != tuple(wav.shape) or \
+                int(out_params.shape[2]) != cfg.teacher_out_width(self.hp):
+            raise ValueError('teacher_log_prob: out_params must be [B,T,{}] and wav [B,T]'.format(cfg.teacher_out_width(self.hp)))
+        lp = torch.empty(tuple(wav.shape), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.wn_teacher_log_prob(self._h, _ptr(out_params), _ptr(wav), int(wav.shape[0]), int(wav.shape[1]),
+                                                     _ptr(lp), self._stream()))
+        return lp
+
     def iaf_cond_hoisted(self, batch, num_frames):
         """True when iaf_generate(batch, num_frames) runs the hoisted-conditioning kernels."""
         return bool(self.lib.wn_iaf_cond_hoisted(self._h, int(batch), int(num_frames)))

@@ -46,6 +46,13 @@ class Wavenet(_TeacherBase):
             raise ValueError('data-dependent initialisation is a training-time feature')
         return {'out_params': self.engine.teacher_forward(inputs['wav'], inputs['mel'])}
 
+    def calculate_loss(self, ff_dict):
+        """wavenet.py:293-316 for scoring audio under the teacher: ff_dict holds 'out_params' (feed_forward) and 'wav' (the raw
+        audio; the reference passes encode_signal's 'real_targets' / 'cate_targets', derived from it -- here the device derives
+        them).  Returns {'loss': -mean log-likelihood, 'log_probs': [B,T]}."""
+        lp = self.engine.teacher_log_prob(ff_dict['out_params'], ff_dict['wav'])
+        return {'loss': -lp.mean(), 'log_probs': lp}
+
 
 class Fastgen(_TeacherBase):
     """Incremental teacher: `sample({'wav': [B,1], 'encoding': [B,Cd]})` is one step.

@@ -351,6 +351,70 @@ def teacher_feed_forward(wav_scaled, mel_en, weights, hp, dtype=np.float32):
 
 
 # --------------------------------------------------------------------------
+# teacher scoring: the per-sample terms of Wavenet.calculate_loss   (wavenet.py:157-178,293-316; loss_func.py:8-63,66-75,104-133)
+# --------------------------------------------------------------------------
+def encode_targets(wav, hp, dtype=np.float32):
+    """wavenet.py:157-178: (real_targets, cate_targets) of Wavenet.encode_signal."""
+    wav = np.asarray(wav, dtype)
+    qc = quant_chann_of(hp)
+    if hp.use_mu_law:
+        xq = mu_law(wav, dtype=dtype)
+        return xq / dtype(qc / 2.), xq.astype(np.int32) + qc // 2
+    return wav, cast_quantize(wav, qc, dtype) + qc // 2
+
+
+def _log_softmax(x):
+    m = x.max(axis=-1, keepdims=True)
+    return x - m - np.log(np.sum(np.exp(x - m), axis=-1, keepdims=True))      # loss_func.py:8-12
+
+
+def mol_log_probs(out, targets, quant_chann, dtype=np.float32):
+    """loss_func.py:22-63 as written (cdf difference and all), log-scale branch.  out [B,T,3M]; targets [B,T]."""
+    out = np.asarray(out, dtype)
+    M = out.shape[-1] // 3
+    logit, means, ls = out[..., :M], out[..., M:2 * M], np.maximum(out[..., 2 * M:], dtype(-7.0))
+    inv = np.exp(-ls)
+    t = np.asarray(targets, dtype)[..., None] + np.zeros([1, 1, M], dtype)
+    c = t - means
+    plus, mn = inv * (c + dtype(1. / quant_chann)), inv * (c - dtype(1. / quant_chann))
+    log_cdf_plus = plus - softplus(plus)
+    log_one_minus_cdf_min = -softplus(mn)
+    delta = sigmoid(plus) - sigmoid(mn)
+    max_thres = (float(quant_chann - 1) - 0.5) / (quant_chann / 2.) - 1.0
+    min_thres = 0.5 / (quant_chann / 2.) - 1.0
+    with np.errstate(divide='ignore'):
+        lp = np.where(t < min_thres, log_cdf_plus,
+                      np.where(t > max_thres, log_one_minus_cdf_min, np.log(np.maximum(delta, dtype(1e-12)))))
+    lp = lp + _log_softmax(logit)
+    m = lp.max(axis=-1)
+    return m + np.log(np.sum(np.exp(lp - m[..., None]), axis=-1))              # loss_func.py:15-19
+
+
+def gauss_log_prob(out, targets, dtype=np.float32):
+    """loss_func.py:66-75,104-119: Normal(mean, exp(max(p, -7))).log_prob(targets)."""
+    out = np.asarray(out, dtype)
+    ls = np.maximum(out[..., 1], dtype(-7.0))
+    z = (np.asarray(targets, dtype) - out[..., 0]) * np.exp(-ls)
+    return -0.5 * z * z - ls - dtype(0.5 * np.log(2.0 * np.pi))
+
+
+def ce_log_prob(out, cate_targets):
+    """loss_func.py:128-133: minus the sparse softmax cross entropy per sample."""
+    ls = _log_softmax(np.asarray(out))
+    return np.take_along_axis(ls, np.asarray(cate_targets)[..., None].astype(np.int64), axis=-1)[..., 0]
+
+
+def teacher_log_prob(out, wav, hp, dtype=np.float32):
+    """Per-sample log-likelihood of the raw audio `wav` [B,T] under out_params [B,T,ow]: what calculate_loss averages."""
+    real, cate = encode_targets(wav, hp, dtype)
+    if hp.loss_type == 'mol':
+        return mol_log_probs(out, real, quant_chann_of(hp), dtype)
+    if hp.loss_type == 'gauss':
+        return gauss_log_prob(out, real, dtype)
+    return ce_log_prob(np.asarray(out, dtype), cate)
+
+
+# --------------------------------------------------------------------------
 # sampling heads with INJECTED randoms   (loss_func.py:66-75,140-206)
 # --------------------------------------------------------------------------
 def mol_sample(out, quant_chann, u_sel, u_x, dtype=np.float32):

@@ -211,8 +211,21 @@ def teacher_case(R, g, out, tag, tmp, w=None):
             vl = var_list()
             tf.train.Saver(ema(tf.trainable_variables())).restore(sess, ckpt)
             requested_ff = list(tf.Saver.requested[-1])
-            out_forced, enc_ff = sess.run([ff['out_params'], ff['encoding']], feed_dict={wav_ph: forced, mel_ph: mel})
+            # teacher scoring: Wavenet.calculate_loss as written (wavenet.py:293-316) and its per-sample term
+            loss_t = wn.calculate_loss({'real_targets': es['real_targets'], 'cate_targets': es['cate_targets'],
+                                        'out_params': ff['out_params']})['loss']
+            if lt == 'mol':
+                logp_t = R.loss_func.mol_log_probs(ff['out_params'], es['real_targets'], Q)
+            elif lt == 'gauss':
+                logp_t = R.loss_func.gauss_log_prob(ff['out_params'], es['real_targets'])
+            else:
+                logp_t = -tf.nn.sparse_softmax_cross_entropy_with_logits(logits=ff['out_params'], labels=es['cate_targets'])
+            out_forced, enc_ff, loss_v, logp_v = sess.run([ff['out_params'], ff['encoding'], loss_t, logp_t],
+                                                          feed_dict={wav_ph: forced, mel_ph: mel})
         assert np.array_equal(enc_ff, enc)
+        assert abs(float(loss_v) + float(np.mean(logp_v))) <= 1e-5 * max(1.0, abs(float(loss_v)))
+        out['{}/logp_{}'.format(tag, fl)] = logp_v
+        out['{}/loss_{}'.format(tag, fl)] = np.array(float(loss_v))
         # -- Fastgen.cond_vars through fastgen.calculate_cond_vars as written
         cond = R.fastgen.calculate_cond_vars(hparams, enc, ckpt)
         # -- the incremental sampler, free running: synthesis() as written ...

@@ -318,6 +318,11 @@ class Normal(object):
     def __init__(self, loc, scale, **kw):
         self.loc, self.scale = convert_to_tensor(loc), convert_to_tensor(scale)
 
+    def log_prob(self, value, name=None):
+        # tf Normal._log_prob: -0.5 * ((x - loc) / scale)^2 - (0.5 * log(2 pi) + log(scale))
+        z = (convert_to_tensor(value, like=self.loc) - self.loc) / self.scale
+        return -0.5 * z * z - (0.5 * np.log(2.0 * np.pi) + log(self.scale))
+
     def sample(self, sample_shape=(), seed=None, name=None):
         base = np.broadcast(self.loc.sample, self.scale.sample).shape
         shape = list(sample_shape) + list(base)
@@ -791,7 +796,17 @@ def _moments(*a, **k):
 
 
 nn.moments = _moments
-nn.sparse_softmax_cross_entropy_with_logits = _moments
+
+
+def _sparse_xent(_sentinel=None, labels=None, logits=None, name=None):
+    def f(lg, lb):
+        m = lg.max(axis=-1, keepdims=True)
+        ls = lg - m - np.log(np.sum(np.exp(lg - m), axis=-1, keepdims=True))
+        return -np.take_along_axis(ls, lb[..., None].astype(np.int64), axis=-1)[..., 0]
+    return _op(f, logits, labels)
+
+
+nn.sparse_softmax_cross_entropy_with_logits = _sparse_xent
 
 
 def _chk(ok):

@@ -356,3 +356,46 @@ def test_engine_full_width_teacher_against_the_reference_code(R, mode, monkeypat
     print('wavenet_mol.json as shipped, {} step: max|out - reference code| = {:.2e} over 400 forced steps; free run identical '
           'for {} of {} steps'.format(mode, err, first, Tn))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# teacher scoring: Wavenet.calculate_loss (wavenet.py:293-316) and its per-sample term, reference code executed
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', TEACHER_GOLD + TEACHER_EXTRA)
+def test_oracle_teacher_scoring_equals_the_reference_code(R, tag):
+    """loss_func.mol_log_probs / gauss_log_prob / the cross entropy on Wavenet.encode_signal's targets, and the scalar
+    Wavenet.calculate_loss returns: oracle equal to float64 rounding."""
+    from oracle import wavenet_np as O
+    g, cfgd, w = _case(R, tag)
+    hp = O.HP(cfgd)
+    ref = R[tag + '/logp_f64']
+    lp = O.teacher_log_prob(R[tag + '/out_forced_f64'], g['forced'], hp, np.float64)
+    assert lp.shape == ref.shape and np.abs(lp - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert abs(-lp.mean() - float(R[tag + '/loss_f64'])) <= 1e-10 * max(1.0, abs(float(R[tag + '/loss_f64'])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', TEACHER_GOLD + TEACHER_EXTRA)
+def test_engine_teacher_scoring_against_the_reference_code(R, tag):
+    """wn_teacher_log_prob on the reference's out_params and on the engine's own (wn_teacher_forward), against the
+    reference's float64 log-likelihoods; Wavenet.calculate_loss of the Python mirror against the reference's scalar."""
+    from nsynth_wavenet_amd.engine import Engine
+    from nsynth_wavenet_amd.wavenet.wavenet import Wavenet
+    g, cfgd, w = _case(R, tag)
+    eng = Engine(cfgd).load_weights(w)
+    ref = R[tag + '/logp_f64']
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    lp = _np(eng.teacher_log_prob(R[tag + '/out_forced_f64'].astype(np.float32), g['forced']))
+    e1 = float(np.abs(lp - ref).max())
+    assert lp.shape == ref.shape and e1 <= tol, (tag, e1)
+    wn = Wavenet(cfgd, engine=eng)
+    ff = wn.feed_forward({'wav': g['forced'], 'mel': g['mel']})
+    res = wn.calculate_loss({'out_params': ff['out_params'], 'wav': g['forced']})
+    e2 = float(np.abs(_np(res['log_probs']) - ref).max())
+    assert e2 <= 10 * tol, (tag, e2)
+    assert abs(float(res['loss']) - float(R[tag + '/loss_f64'])) <= 2e-5 * max(1.0, abs(float(R[tag + '/loss_f64'])))
+    with pytest.raises(ValueError):
+        eng.teacher_log_prob(np.zeros([2, 8, 3], np.float32), np.zeros([2, 8], np.float32))
+    print('{}: max|log p - reference code| = {:.2e} on the reference\'s out_params, {:.2e} end to end (range {:.1f}); loss {:.6f} vs {:.6f}'.format(
+        tag, e1, e2, float(np.abs(ref).max()), float(res['loss']), float(R[tag + '/loss_f64'])))
+    eng.close()
