@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_json  # noqa: F401
+from conftest import load_json
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 STUDENT_GOLD = ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw']
