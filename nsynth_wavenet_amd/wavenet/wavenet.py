@@ -37,6 +37,19 @@ class Wavenet(_TeacherBase):
     def deconv_stack(self, mel_inputs, init=False):
         return {'encoding': self.engine.deconv(mel_inputs['mel'])}
 
+    def encode_signal(self, inputs):
+        """wavenet.py:157-178 on the host (numpy): 'wav' [B,T] -> 'wav_scaled' (the network input), 'real_targets', 'cate_targets'.
+        feed_forward / calculate_loss take the raw 'wav' and derive these on the device; this is the reference's function for
+        callers that want the targets themselves."""
+        from ..auxilaries import utils
+        x = np.asarray(inputs['wav'], np.float32)
+        q = self.quant_chann
+        if self.use_mu_law:
+            xq = utils.mu_law_numpy(x, mu=np.float32(255))          # float32 arithmetic, like the TF twin (utils.py:72-87)
+            scaled = (xq / np.float32(q / 2.)).astype(np.float32)
+            return {'wav_scaled': scaled, 'real_targets': scaled, 'cate_targets': xq.astype(np.int32) + q // 2}
+        return {'wav_scaled': x, 'real_targets': x, 'cate_targets': np.floor(x * np.float32(q / 2)).astype(np.int32) + q // 2}
+
     def feed_forward(self, inputs, init=False):
         """wavenet.py:180-291 with 'wav' [B,T] raw audio and 'mel' [B,F,80]: the reference derives
         'wav_scaled' from 'wav' (wavenet.py:157-178); here the device does.  Returns 'out_params'

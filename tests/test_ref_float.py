@@ -394,6 +394,10 @@ def test_engine_teacher_scoring_against_the_reference_code(R, tag):
     e2 = float(np.abs(_np(res['log_probs']) - ref).max())
     assert e2 <= 10 * tol, (tag, e2)
     assert abs(float(res['loss']) - float(R[tag + '/loss_f64'])) <= 2e-5 * max(1.0, abs(float(R[tag + '/loss_f64'])))
+    from oracle import wavenet_np as O
+    es = wn.encode_signal({'wav': g['forced']})
+    real, cate = O.encode_targets(g['forced'], O.HP(cfgd), np.float32)
+    assert np.array_equal(es['real_targets'], real) and np.array_equal(es['cate_targets'], cate) and es['wav_scaled'] is es['real_targets']
     with pytest.raises(ValueError):
         eng.teacher_log_prob(np.zeros([2, 8, 3], np.float32), np.zeros([2, 8], np.float32))
     print('{}: max|log p - reference code| = {:.2e} on the reference\'s out_params, {:.2e} end to end (range {:.1f}); loss {:.6f} vs {:.6f}'.format(
