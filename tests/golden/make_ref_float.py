@@ -373,6 +373,63 @@ def teacher_full_width_case(R, out, tmp):
     print(tag, 'Tn', Tn, 'out range', float(np.abs(res['forced'][1]).max()))
 
 
+def k8_cases(R, out, tmp):
+    """The shapes and seeds of the reference's own hot-path tests, through the reference's code, float64:
+    tests/test_parallel_wavenet.py:25-31 -- four utterances of 39 frames = 7 680 samples, the student JSONs AS SHIPPED
+    (parallel_wavenet.json: shared upsampler; parallel_wavenet_gauss.json: four private ones, normal noise);
+    tests/test_fastgen.py:17-32 -- ONE step of Fastgen.sample on wavenet_mol.json as shipped, batch 4, wav [4,1] and
+    encoding [4,256] drawn U(-1,1) after np.random.seed(12345) exactly as that test draws them (its TF-initialised
+    weights are replaced by the synthetic ones below; the reference prints the sample, here the network output is kept)."""
+    for tag, name in (('k8_pw', 'parallel_wavenet.json'), ('k8_pw_gauss', 'parallel_wavenet_gauss.json')):
+        cfgd = repo_cfg(name)
+        hp = cfgmod.load_hparams(cfgd)
+        w = wts.synthetic_weights(hp, seed=1234, init='unit')
+        g = {'cfg_json': np.array(json.dumps(cfgd)), 'seed': np.array(1234), 'init': np.array('unit'),
+             'mel': np.random.RandomState(51).uniform(0, 1, [4, 39, 80]).astype(np.float32)}
+        tmp_out = {}
+        student_case(R, g, tmp_out, tag, tmp, w, floats=(('f64', np.float64),))
+        for k in ('x_f64', 'vars', 'ckpt_keys', 'kind'):
+            out['{}/{}'.format(tag, k)] = tmp_out['{}/{}'.format(tag, k)]
+        # the noise is not stored: the tests recompute it from the seeded float32 draws student_case injected
+        rs = np.random.RandomState(12346)
+        d = (rs.standard_normal([4, 7680]) if cfgd['loss_type'] == 'gauss' else rs.uniform(1e-5, 1 - 1e-5, [4, 7680]))
+        d = d.astype(np.float32).astype(np.float64)
+        d = d if cfgd['loss_type'] == 'gauss' else np.log(d) - np.log(1.0 - d)
+        assert np.abs(d - tmp_out[tag + '/rand_input_f64']).max() <= 1e-14
+        out[tag + '/scale_tot_f32'] = tmp_out[tag + '/scale_tot_f64'].astype(np.float32)
+        for k, v in g.items():
+            out['{}/in_{}'.format(tag, k)] = v
+    tag = 'k8_fastgen'
+    cfgd = repo_cfg('wavenet_mol.json')
+    hp = cfgmod.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=1234, init='unit')
+    ckpt = wts.save_checkpoint(os.path.join(tmp, tag + '.npz'), w, hp)
+    B = 4
+    np.random.seed(12345)                                   # tests/test_fastgen.py:28-30
+    wav_val = np.random.uniform(-1, 1, [B, 1])
+    mel_en_val = np.random.uniform(-1, 1, [B, cfgd['deconv_width']])
+    M = cfgd['mol_mix']
+    rnd = np.random.RandomState(52).uniform(1e-5, 1 - 1e-5, [1, B, M + 1]).astype(np.float32)
+    tf.set_float(np.float64)
+    tf.set_random_source(TableSource({0: lambda t: rnd[t][:, :M].reshape(B, 1, M), 1: lambda t: rnd[t][:, M].reshape(B, 1)}))
+    with tf.Graph().as_default(), tf.Session() as sess:
+        fgen = R.wavenet.Fastgen(reference_hparams(cfgd, 'teacher'), B)          # tests/test_fastgen.py:17-27
+        wav_ph = tf.placeholder(tf.float32, [B, 1])
+        mel_en_ph = tf.placeholder(tf.float32, [B, cfgd['deconv_width']])
+        fg = fgen.sample({'wav': wav_ph, 'encoding': mel_en_ph})
+        out_node = find_bias_add(fg['sample'], 'out2/biases')
+        tf.train.Saver(R.fastgen.get_ema_shadow_dict(tf.trainable_variables())).restore(sess, ckpt)
+        sess.run(fg['init_ops'])
+        s_val, o_val, _ = sess.run([fg['sample'], out_node, fg['push_ops']], feed_dict={wav_ph: wav_val, mel_en_ph: mel_en_val})
+    out[tag + '/wav'] = wav_val.astype(np.float32)
+    out[tag + '/encoding'] = mel_en_val.astype(np.float32)
+    out[tag + '/rnd'] = rnd
+    out[tag + '/out_f64'] = o_val
+    out[tag + '/sample'] = s_val.astype(np.int32)
+    out[tag + '/in_cfg_json'] = np.array(json.dumps(cfgd))
+    print(tag, 'sample', s_val[:, 0], 'out range', float(np.abs(o_val).max()))
+
+
 def full_size_case(R, tmp):
     """BASELINE.json configs[1] at its full size -- parallel_wavenet.json as shipped, one utterance of 384 frames = 76 800
     samples, bench.py's weights (synthetic_weights(seed=1234, init='tf')) -- through parallelgen.synthesis as written, float64.
@@ -415,6 +472,7 @@ def main():
             teacher_case(R, np.load(os.path.join(HERE, tag + '.npz')), out, tag, tmp)
         extra_cases(R, out, tmp)
         teacher_full_width_case(R, out, tmp)
+        k8_cases(R, out, tmp)
     out['numpy_version'] = np.array(np.__version__)
     # the float32-arithmetic twins are kept for the principal outputs only
     for k in [k for k in out if k.endswith('_f32') and k.split('/')[1].rsplit('_', 1)[0] not in

@@ -403,3 +403,79 @@ def test_engine_teacher_scoring_against_the_reference_code(R, tag):
     print('{}: max|log p - reference code| = {:.2e} on the reference\'s out_params, {:.2e} end to end (range {:.1f}); loss {:.6f} vs {:.6f}'.format(
         tag, e1, e2, float(np.abs(ref).max()), float(res['loss']), float(R[tag + '/loss_f64'])))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the shapes and seeds of the reference's own hot-path tests, through the reference's code
+# ------------------------------------------------------------------------------------------------------------------
+def _k8_noise(gauss):
+    rs = np.random.RandomState(12346)
+    d = (rs.standard_normal([4, 7680]) if gauss else rs.uniform(1e-5, 1 - 1e-5, [4, 7680])).astype(np.float32).astype(np.float64)
+    return d if gauss else np.log(d) - np.log(1.0 - d)
+
+
+@pytest.mark.parametrize('tag', ['k8_pw', 'k8_pw_gauss'])
+def test_oracle_equals_the_reference_code_on_the_reference_test_shape(R, tag):
+    """tests/test_parallel_wavenet.py:25-31: four utterances of 39 frames = 7 680 samples, the student JSONs as shipped."""
+    from oracle import wavenet_np as O
+    g, cfgd, w = _case(R, tag)
+    assert cfgd == load_json('parallel_wavenet_gauss.json' if tag.endswith('gauss') else 'parallel_wavenet.json')
+    hp = O.HP(cfgd)
+    ff = O.iaf_feed_forward(g['mel'], _k8_noise(hp.loss_type == 'gauss'), w, hp, np.float64)
+    ref = R[tag + '/x_f64']
+    assert ff['x'].shape == (4, 7680) and np.abs(ff['x'] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    assert np.abs(ff['scale_tot'] - R[tag + '/scale_tot_f32']).max() <= 1e-6 * max(1.0, np.abs(ff['scale_tot']).max())
+
+
+def test_oracle_equals_the_reference_code_on_the_fastgen_test_step(R):
+    """tests/test_fastgen.py:17-32: one step of Fastgen.sample, wavenet_mol.json as shipped, batch 4, its seed-12345 inputs."""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    cfgd = json.loads(str(R['k8_fastgen/in_cfg_json']))
+    np.random.seed(12345)
+    assert np.array_equal(np.random.uniform(-1, 1, [4, 1]).astype(np.float32), R['k8_fastgen/wav'])
+    hp = O.HP(cfgd)
+    w = wts.synthetic_weights(cfg.load_hparams(cfgd), seed=1234, init='unit')
+    fg = O.Fastgen(w, hp, 4, np.float64)
+    out = fg.out_params(R['k8_fastgen/wav'].astype(np.float64), R['k8_fastgen/encoding'].astype(np.float64))
+    # (the reference fed the float64 draws; the fixture keeps their float32 rounding, what the device takes)
+    assert np.abs(out - R['k8_fastgen/out_f64'][:, :]).max() <= 2e-6
+    assert np.array_equal(fg.sample_from(R['k8_fastgen/out_f64'], R['k8_fastgen/rnd'][0]), R['k8_fastgen/sample'][:, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['k8_pw', 'k8_pw_gauss'])
+def test_engine_against_the_reference_code_on_the_reference_test_shape(R, tag):
+    from nsynth_wavenet_amd.engine import Engine
+    g, cfgd, w = _case(R, tag)
+    eng = Engine(cfgd).load_weights(w)
+    noise = _k8_noise(cfgd['loss_type'] == 'gauss')
+    out = eng.iaf_generate(g['mel'], noise.astype(np.float32), want=('x', 'scale_tot'))
+    ref = R[tag + '/x_f64']
+    err = float(np.abs(_np(out['x']) - ref).max())
+    assert err <= 2e-5 * max(1.0, float(np.abs(ref).max())), (tag, err)
+    st = R[tag + '/scale_tot_f32']
+    assert np.abs(_np(out['scale_tot']) - st).max() <= 2e-5 * max(1.0, float(np.abs(st).max()))
+    print('{}: max|x - reference code| = {:.2e} on a range of {:.1f} (range fallbacks {})'.format(
+        tag, err, float(np.abs(ref).max()), getattr(eng, 'range_fallbacks', 0)))
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_engine_against_the_reference_code_on_the_fastgen_test_step(R):
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    from nsynth_wavenet_amd import weights as wts, config as cfg
+    cfgd = json.loads(str(R['k8_fastgen/in_cfg_json']))
+    w = wts.synthetic_weights(cfg.load_hparams(cfgd), seed=1234, init='unit')
+    eng = Engine(cfgd).load_weights(w)
+    st = eng.ar_new_state(4)
+    s, op = eng.ar_step(st, R['k8_fastgen/wav'][:, 0], R['k8_fastgen/encoding'], R['k8_fastgen/rnd'][0], want_out=True)
+    ref = R['k8_fastgen/out_f64']
+    err = float(np.abs(_np(op) - ref).max())
+    assert err <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    i64, margin, gap = O.sample_margin(_np(op), R['k8_fastgen/rnd'][0], O.HP(cfgd))
+    d = _np(s).astype(np.int64) - R['k8_fastgen/sample'][:, 0]
+    assert np.all((d == 0) | ((np.abs(d) <= 1) & (margin <= 0.02)) | (gap <= 1e-5))
+    print('test_fastgen.py step: max|out - reference code| = {:.2e}; sample {} vs {}'.format(err, _np(s), R['k8_fastgen/sample'][:, 0]))
+    eng.close()
