@@ -22,7 +22,7 @@ SYMBOLS = ['wn_abi_version', 'wn_create', 'wn_set_weight', 'wn_finalize', 'wn_ia
            'wn_iaf_workspace_bytes_form', 'wn_iaf_range_status', 'wn_iaf_range_reset',
            'wn_iaf_range_status_since_reset', 'wn_clip_quant',
            'wn_ar_n_rand', 'wn_ar_state_bytes', 'wn_ar_reset', 'wn_ar_step', 'wn_ar_generate', 'wn_ar_set_graph', 'wn_ar_cond_vars', 'wn_ar_cond_vars_floats',
-           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_teacher_log_prob', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_profile_parts_only', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy']
+           'wn_iaf_cond_hoisted', 'wn_iaf_layer_groups', 'wn_iaf_set_groups', 'wn_teacher_workspace_bytes', 'wn_teacher_forward', 'wn_teacher_log_prob', 'wn_profile_begin', 'wn_profile_pause', 'wn_profile_end', 'wn_profile_parts_begin', 'wn_profile_parts_end', 'wn_profile_parts_only', 'wn_mel_frames', 'wn_mel_spectrogram', 'wn_last_error', 'wn_destroy', 'wn_crc32c']
 
 
 class WnConfig(ctypes.Structure):
@@ -108,6 +108,8 @@ def load():
     lib.wn_last_error.restype = c.c_char_p
     lib.wn_destroy.argtypes = [vp]
     lib.wn_destroy.restype = None
+    lib.wn_crc32c.argtypes = [c.c_char_p, sz, c.c_uint32]
+    lib.wn_crc32c.restype = c.c_uint32
     for s in SYMBOLS:
         getattr(lib, s)
     if lib.wn_abi_version() != 1:

@@ -22,6 +22,9 @@ LIB_PATH = os.path.join(LIB_DIR, os.environ.get('WN_LIB_NAME', 'libwnhip.so'))  
 # instruction with selects at all (scripts/audit_store_hazard.py checks it), and the kernels are no slower (measured
 # 58.4-59.3 against 60.8-61.1 us per group launch on one box).
 CODEGEN_FLAGS = ['-O3', '-std=c++17', '-fno-slp-vectorize']
+# The C ABI of include/wnhip.h (WN_API = default visibility) is the library's whole dynamic symbol table: everything
+# else -- the C++ helpers shared by the translation units, STL instantiations -- is local to it.
+VISIBILITY_FLAGS = ['-fvisibility=hidden', '-fvisibility-inlines-hidden']
 SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_x.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
 HEADERS = ['wn_internal.h', 'wn_codec.h', 'wn_pack_h.h', 'wn_mfma_h.h', 'wn_iaf_c.h', os.path.join(ROOT, 'include', 'wnhip.h')]
 
@@ -51,7 +54,7 @@ def source_hash():
         hh.update(os.path.basename(d).encode() + b'\0')
         with open(d, 'rb') as f:
             hh.update(f.read())
-    hh.update(' '.join(CODEGEN_FLAGS).encode())
+    hh.update(' '.join(CODEGEN_FLAGS + VISIBILITY_FLAGS).encode())
     hh.update(os.environ.get('WN_EXTRA_FLAGS', '').encode())
     return hh.hexdigest()
 
@@ -86,7 +89,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     hipcc = find_hipcc()
-    common = ['--offload-arch=gfx950'] + CODEGEN_FLAGS + ['-fPIC', '-Wall',
+    common = ['--offload-arch=gfx950'] + CODEGEN_FLAGS + VISIBILITY_FLAGS + ['-fPIC', '-Wall',
               '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + \
         os.environ.get('WN_EXTRA_FLAGS', '').split()
     procs = []
@@ -110,7 +113,12 @@ def build(force=False, verbose=True):
     # src1 select (hazard_audit.py).  The kernels are exact only as long as the compiler's output keeps
     # clear of them, so a compiler that reintroduces one must not produce a library.
     audit_objects(objs, verbose)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_PATH]
+    # ... and what -fvisibility=hidden cannot reach (libstdc++'s template instantiations carry their own default-visibility
+    # attribute, hipcc adds one __hip_cuid_* per translation unit) is made local by a linker version script
+    vers = os.path.join(LIB_DIR, 'libwnhip.map')
+    with open(vers, 'w') as f:
+        f.write('{ global: wn_*; local: *; };\n')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + VISIBILITY_FLAGS + ['-Wl,--version-script=' + vers] + objs + ['-o', LIB_PATH]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -900,15 +900,25 @@ void ar_enqueue_step(wn_handle* h, float* state, int B, const float* wav_in, con
         }
 }
 
+// The hipGraphs of ONE wn_ar_generate call.  They must outlive the call (it returns before its stream has run them), so
+// the handle keeps a list: every call adds its own entry, and retires the entries whose `done` event -- recorded behind
+// the last replay -- has passed.  Nothing of a call's graphs is shared with another call: concurrent callers of one
+// handle (each with its own state buffer and stream) never touch each other's entries.
 struct ArGraphCache {
     hipGraphExec_t exec_multi = nullptr, exec_one = nullptr;
     hipGraph_t g_multi = nullptr, g_one = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
 };
 
 void ar_cache_free(ArGraphCache* c) {
     if (!c) return;
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->done) {
+        (void)hipEventSynchronize(c->done);
+        (void)hipEventDestroy(c->done);
+    } else if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+    }
     if (c->exec_multi) (void)hipGraphExecDestroy(c->exec_multi);
     if (c->exec_one) (void)hipGraphExecDestroy(c->exec_one);
     if (c->g_multi) (void)hipGraphDestroy(c->g_multi);
@@ -919,8 +929,29 @@ void ar_cache_free(ArGraphCache* c) {
 }  // namespace
 
 void wn_ar_release(wn_handle* h) {
-    ar_cache_free(reinterpret_cast<ArGraphCache*>(h->ar_graph_cache));
-    h->ar_graph_cache = nullptr;
+    std::vector<void*> all;
+    {
+        std::lock_guard<std::mutex> g(h->list_mu);
+        all.swap(h->ar_graphs);
+    }
+    for (void* p : all) ar_cache_free(reinterpret_cast<ArGraphCache*>(p));
+}
+
+// entries whose stream has finished replaying them
+static void ar_retire_finished(wn_handle* h) {
+    std::vector<void*> gone;
+    {
+        std::lock_guard<std::mutex> g(h->list_mu);
+        size_t k = 0;
+        for (void* p : h->ar_graphs) {
+            ArGraphCache* c = reinterpret_cast<ArGraphCache*>(p);
+            if (c->done && hipEventQuery(c->done) == hipSuccess) gone.push_back(p);
+            else h->ar_graphs[k++] = p;
+        }
+        h->ar_graphs.resize(k);
+    }
+    (void)hipGetLastError();                   // hipEventQuery's hipErrorNotReady is not an error of this call
+    for (void* p : gone) ar_cache_free(reinterpret_cast<ArGraphCache*>(p));
 }
 
 // ---------------------------------------------------------------------------
@@ -1117,6 +1148,7 @@ extern "C" int wn_ar_step(wn_handle* h, void* state, int B, const float* wav_in,
                           const float* rnd, uint64_t seed, int32_t* sample, float* out_params, void* stream) {
     int rc = ar_check(h, "wn_ar_step", B);
     if (rc) return rc;
+    const WnWork work(h);
     if (!state || !wav_in || !enc_t || !sample) return wn_fail(h, WN_EINVAL, "wn_ar_step: null argument");
     ar_enqueue_step(h, reinterpret_cast<float*>(state), B, wav_in, nullptr, enc_t, 1, 1, rnd, seed, sample,
                     nullptr, out_params, reinterpret_cast<hipStream_t>(stream));
@@ -1129,6 +1161,8 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
                               size_t ws_bytes, void* stream) {
     int rc = ar_check(h, "wn_ar_generate", B);
     if (rc) return rc;
+    const WnWork work(h);                       // wn_ar_set_graph is refused until this call returns; read once:
+    const bool use_graph = h->ar_use_graph;
     if (Tn < 0) return wn_fail(h, WN_EINVAL, "wn_ar_generate: negative length");
     if (Tn == 0) return WN_OK;
     if (!enc || !ws || (!idx && !wav)) return wn_fail(h, WN_EINVAL, "wn_ar_generate: null argument");
@@ -1146,14 +1180,13 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     };
     // The legacy null stream cannot be captured; WN_AR_GRAPH=0 forces plain launches (A/B runs, tests).
     const char* eg = getenv("WN_AR_GRAPH");
-    if (!st || !h->ar_use_graph || (eg && eg[0] == '0')) return plain(Tn);
+    if (!st || !use_graph || (eg && eg[0] == '0')) return plain(Tn);
     // Every per-step address is derived on the device from the step counter, so a captured step is static:
     // build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay.  A failed capture is always closed (the
     // caller's stream must not be left in capture mode), its partial graph destroyed, and the call falls
     // back to plain launches.
-    wn_ar_release(h);
+    ar_retire_finished(h);
     ArGraphCache* gc = new ArGraphCache();
-    h->ar_graph_cache = gc;
     gc->stream = st;
     auto capture = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1179,11 +1212,20 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     if (multi) ok = capture(AR_GRAPH_STEPS, &gc->g_multi, &gc->exec_multi);
     if (ok && rest) ok = capture(1, &gc->g_one, &gc->exec_one);
     if (!ok) {
-        wn_ar_release(h);
+        gc->stream = nullptr;                   // nothing of it was launched
+        ar_cache_free(gc);
         return plain(Tn);
     }
-    for (int i = 0; i < multi; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_multi, st));
-    for (int i = 0; i < rest; ++i) WN_HIP(h, hipGraphLaunch(gc->exec_one, st));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < multi && e == hipSuccess; ++i) e = hipGraphLaunch(gc->exec_multi, st);
+    for (int i = 0; i < rest && e == hipSuccess; ++i) e = hipGraphLaunch(gc->exec_one, st);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&gc->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(gc->done, st);
+    {
+        std::lock_guard<std::mutex> g(h->list_mu);
+        h->ar_graphs.push_back(gc);             // kept until its stream has run it (ar_retire_finished / wn_destroy)
+    }
+    if (e != hipSuccess) return wn_fail(h, WN_EIO, "wn_ar_generate: graph replay failed: %s", hipGetErrorString(e));
     return WN_OK;
 }
 
@@ -1267,6 +1309,7 @@ extern "C" int wn_ar_cond_vars(wn_handle* h, const float* enc, int B, int Tn, fl
 
 extern "C" int wn_ar_set_graph(wn_handle* h, int enable) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_ar_set_graph: null handle");
+    WN_SWITCH(h, "wn_ar_set_graph");
     h->ar_use_graph = enable != 0;
     return WN_OK;
 }

@@ -1030,6 +1030,7 @@ extern "C" int wn_deconv(wn_handle* h, const char* scope, const float* mel, int 
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_deconv: null handle");
     if (!h->finalized) return wn_fail(h, WN_ESTATE, "wn_deconv: call wn_finalize first");
     if (!mel || !enc || !ws || B < 1 || F < 1) return wn_fail(h, WN_EINVAL, "wn_deconv: bad argument");
+    const WnWork work(h);
     int si = -1;
     for (size_t i = 0; i < h->stacks.size(); ++i)
         if (h->stacks[i].prefix == (scope ? scope : "")) si = (int)i;

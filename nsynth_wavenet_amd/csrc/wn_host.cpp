@@ -8,15 +8,14 @@
 #include <cstdlib>
 #include "wn_internal.h"
 
-static std::string g_create_err;
+// Last error message of the calling thread: concurrent callers of one handle never share (or tear) a string.
+static thread_local char t_err[1024] = "";
 
-int wn_fail(const wn_handle* h, int code, const char* fmt, ...) {
-    char buf[1024];
+int wn_fail(const wn_handle*, int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
     va_end(ap);
-    if (h) h->err = buf; else g_create_err = buf;
     return code;
 }
 
@@ -185,6 +184,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         const char* fg = getenv("WN_GROUPS");
         if (ng && atoi(ng) != 0) h->groups_env = -1;
         else if (fg && atoi(fg) != 0) h->groups_env = 1;
+        h->groups_env0 = h->groups_env;
     }
     if (const char* e = getenv("WN_COND")) {                         // read ONCE: sizing and generate calls must agree
         if (!strcmp(e, "fused")) h->cond_env_mode = WN_COND_FUSED;
@@ -328,13 +328,13 @@ extern "C" size_t wn_iaf_workspace_bytes_form(const wn_handle* h, int form, int 
     return wn_iaf_workspace_bytes(h, B, F, form);
 }
 
-extern "C" const char* wn_last_error(const wn_handle* h) {
-    return h ? h->err.c_str() : g_create_err.c_str();
-}
+extern "C" const char* wn_last_error(const wn_handle*) { return t_err; }
 
 extern "C" void wn_destroy(wn_handle* h) {
     if (!h) return;
     wn_ar_release(h);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);
     if (h->d_blob) (void)hipFree(h->d_blob);
     delete h;
 }
@@ -367,11 +367,11 @@ std::vector<float> wn_get_kernel(const wn_handle* h, const std::string& scope, c
 }
 
 // ---- CRC32C (Castagnoli) for the TensorFlow checkpoint reader/writer (tf_bundle.py) ----
-// Internal helper, not part of wnhip.h: slicing-by-8 table lookup on the host.
-extern "C" uint32_t wnx_crc32c(const void* data, size_t n, uint32_t crc) {
+// Slicing-by-8 table lookup on the host (wnhip.h: wn_crc32c).
+extern "C" uint32_t wn_crc32c(const void* data, size_t n, uint32_t crc) {
     static uint32_t T[8][256];
-    static bool init = false;
-    if (!init) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
@@ -379,8 +379,7 @@ extern "C" uint32_t wnx_crc32c(const void* data, size_t n, uint32_t crc) {
         }
         for (uint32_t i = 0; i < 256; ++i)
             for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
-        init = true;
-    }
+    });
     const unsigned char* p = static_cast<const unsigned char*>(data);
     uint32_t c = crc ^ 0xffffffffu;
     while (n >= 8) {

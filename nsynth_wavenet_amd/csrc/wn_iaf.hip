@@ -705,6 +705,11 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     if (h->cfg.kind != WN_KIND_STUDENT)
         return wn_fail(h, WN_EINVAL, "wn_iaf_generate: handle is not a ParallelWavenet student");
     if (B < 1 || F < 1) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: B and F must be >= 1");
+    // inside the library from here on: the switches (wn_iaf_set_groups, wn_profile_*) are refused until the call returns,
+    // and each of them is read ONCE, here
+    const WnWork work(h);
+    const bool prof_on = h->prof_on, parts_on = h->parts_on;
+    const int pmask = parts_on ? h->parts_mask : 0xf;   // a restriction exists only inside a parts session (wn_profile_parts_only)
     const IafLayout L = iaf_layout(h, B, F, form);
     if (L.T == 0) return WN_OK;   // fewer frames than one max-dilation block: empty output
     if (!mel || !wav || !ws) return wn_fail(h, WN_EINVAL, "wn_iaf_generate: null mel/wav/workspace");
@@ -738,15 +743,26 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     // measurement aid (wn_profile_parts_begin): an event where a part of the call begins.  Parts: 0 prologue / epilogue
     // (pads, noise, final), 1 upsampler, 2 conditioning GEMM, 3 residual stack (start convs, layers, heads)
     int part_now = -2;
-    auto part = [&](int tag) -> int {
-        if (!h->parts_on || tag == part_now) return WN_OK;
+    constexpr size_t MAX_PART_EVENTS = 4096;            // a power loop of thousands of calls stops recording, not allocating
+    auto record = [&](std::vector<hipEvent_t>& list, int tag) -> int {
         hipEvent_t ev;
         WN_HIP(h, hipEventCreate(&ev));
-        h->part_events.push_back(ev);
-        h->part_tags.push_back(tag);
+        {
+            std::lock_guard<std::mutex> g(h->list_mu);
+            list.push_back(ev);
+            if (&list == &h->part_events) h->part_tags.push_back(tag);
+        }
         WN_HIP(h, hipEventRecord(ev, st));
-        part_now = tag;
         return WN_OK;
+    };
+    auto part = [&](int tag) -> int {
+        if (!parts_on || tag == part_now) return WN_OK;
+        part_now = tag;
+        {
+            std::lock_guard<std::mutex> g(h->list_mu);
+            if (h->part_events.size() >= MAX_PART_EVENTS) return WN_OK;
+        }
+        return record(h->part_events, tag);
     };
     if (int rc = part(0)) return rc;
     // prologue: zero left pads + the flow input (drawn on the device, or the caller's noise), one launch
@@ -771,7 +787,6 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     auto blob_u = [&](size_t off) { return reinterpret_cast<const unsigned*>(h->d_blob + off); };
     const unsigned* cond_tab = blob_u(h->cond_tab_off);
     const size_t rb_floats = (size_t)(L.T / 16) * 1024;     // C floats of one row block
-    const int pmask = h->parts_mask;                     // (0xf except under wn_profile_parts_only)
     if (c.share_deconv) {
         if (int rc = part(1)) return rc;
         int rc = (pmask & 2) ? wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec) : WN_OK;
@@ -808,12 +823,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
             // from x, the last one runs the flow head
             float* gin = lA;
             float* gout = lB;
-            if (h->prof_on) {
-                hipEvent_t ev;
-                WN_HIP(h, hipEventCreate(&ev));
-                h->prof_events.push_back(ev);
-                WN_HIP(h, hipEventRecord(ev, st));
-            }
+            if (prof_on) if (int rc = record(h->prof_events, 0)) return rc;
             for (size_t gi = 0; gi < fp.groups.size(); ++gi) {
                 const WnGroup& g = fp.groups[gi];
                 const bool lastg = gi + 1 == fp.groups.size();
@@ -827,11 +837,9 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
                 x = xnew;
                 std::swap(gin, gout);
             }
-            if (h->prof_on) {
-                hipEvent_t ev;
-                WN_HIP(h, hipEventCreate(&ev));
-                h->prof_events.push_back(ev);
-                WN_HIP(h, hipEventRecord(ev, st));
+            if (prof_on) {
+                if (int rc = record(h->prof_events, 0)) return rc;
+                std::lock_guard<std::mutex> g(h->list_mu);
                 h->prof_launches += (int64_t)fp.groups.size();
             }
             continue;
@@ -856,15 +864,15 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         // (the dominant kernel); two-layer launches and heads stay outside the brackets
         bool prof_open = false;
         auto prof_mark = [&](bool open, int launches) -> int {
-            if (!h->prof_on) return WN_OK;
+            if (!prof_on) return WN_OK;
             if (open != prof_open) {
-                hipEvent_t ev;
-                WN_HIP(h, hipEventCreate(&ev));
-                h->prof_events.push_back(ev);
-                WN_HIP(h, hipEventRecord(ev, st));
+                if (int rc = record(h->prof_events, 0)) return rc;
                 prof_open = open;
             }
-            if (open) h->prof_launches += launches;
+            if (open) {
+                std::lock_guard<std::mutex> g(h->list_mu);
+                h->prof_launches += launches;
+            }
             return WN_OK;
         };
         size_t li = 0;
@@ -929,7 +937,10 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
             WN_HIP(h, hipMemcpyAsync(rand_out, x0, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     if (int rc = part(-1)) return rc;
-    if (h->parts_on) ++h->part_calls;
+    if (parts_on) {
+        std::lock_guard<std::mutex> g(h->list_mu);
+        ++h->part_calls;
+    }
     WN_HIP(h, hipGetLastError());
     return WN_OK;
 }
@@ -1011,8 +1022,9 @@ bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int form) {
 
 extern "C" int wn_iaf_set_groups(wn_handle* h, int mode) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_iaf_set_groups: null handle");
-    if (mode < -1 || mode > 1) return wn_fail(h, WN_EINVAL, "wn_iaf_set_groups: mode must be -1 (never), 0 (policy) or 1 (always), got %d", mode);
-    h->groups_env = mode;
+    if (mode < -1 || mode > 1) return wn_fail(h, WN_EINVAL, "wn_iaf_set_groups: mode must be -1 (never), 0 (as created) or 1 (always), got %d", mode);
+    WN_SWITCH(h, "wn_iaf_set_groups");
+    h->groups_env = mode ? mode : h->groups_env0;      // 0: what wn_create resolved (the size policy, or WN_GROUPS / WN_NO_GROUPS)
     return WN_OK;
 }
 
@@ -1069,6 +1081,7 @@ extern "C" int wn_iaf_range_status_since_reset(wn_handle* h, void* ws, void* str
 
 extern "C" int wn_profile_begin(wn_handle* h) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_begin: null handle");
+    WN_SWITCH(h, "wn_profile_begin");
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     h->prof_events.clear();
     h->prof_launches = 0;
@@ -1078,10 +1091,12 @@ extern "C" int wn_profile_begin(wn_handle* h) {
 
 extern "C" int wn_profile_parts_begin(wn_handle* h) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_begin: null handle");
+    WN_SWITCH(h, "wn_profile_parts_begin");
     for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);
     h->part_events.clear();
     h->part_tags.clear();
     h->part_calls = 0;
+    h->parts_mask = 0xf;
     h->parts_on = true;
     return WN_OK;
 }
@@ -1089,25 +1104,32 @@ extern "C" int wn_profile_parts_begin(wn_handle* h) {
 extern "C" int wn_profile_parts_only(wn_handle* h, int mask) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_only: null handle");
     if (mask < 1 || mask > 0xf) return wn_fail(h, WN_EINVAL, "wn_profile_parts_only: mask must be in 1..15, got %d", mask);
+    WN_SWITCH(h, "wn_profile_parts_only");
+    if (!h->parts_on)      // a restricted call skips work: the switch lives and dies with a measurement session
+        return wn_fail(h, WN_ESTATE, "wn_profile_parts_only: only between wn_profile_parts_begin and wn_profile_parts_end");
     h->parts_mask = mask;
     return WN_OK;
 }
 
 extern "C" int wn_profile_parts_end(wn_handle* h, double* part_ms, int64_t* calls) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_parts_end: null handle");
+    WN_SWITCH(h, "wn_profile_parts_end");
     h->parts_on = false;
+    h->parts_mask = 0xf;                                           // never left armed
     double ms[WN_PROFILE_PARTS] = {0.0};
-    for (size_t i = 0; i + 1 < h->part_events.size(); ++i) {
+    hipError_t bad = hipSuccess;
+    for (size_t i = 0; i + 1 < h->part_events.size() && bad == hipSuccess; ++i) {
         const int tag = h->part_tags[i];
         if (tag < 0 || tag >= WN_PROFILE_PARTS) continue;          // -1: between two calls
         float f = 0.f;
-        WN_HIP(h, hipEventSynchronize(h->part_events[i + 1]));
-        WN_HIP(h, hipEventElapsedTime(&f, h->part_events[i], h->part_events[i + 1]));
+        bad = hipEventSynchronize(h->part_events[i + 1]);
+        if (bad == hipSuccess) bad = hipEventElapsedTime(&f, h->part_events[i], h->part_events[i + 1]);
         ms[tag] += f;
     }
-    for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->part_events) (void)hipEventDestroy(e);   // (on the error path as well)
     h->part_events.clear();
     h->part_tags.clear();
+    if (bad != hipSuccess) return wn_fail(h, WN_EIO, "wn_profile_parts_end: %s", hipGetErrorString(bad));
     if (part_ms) for (int i = 0; i < WN_PROFILE_PARTS; ++i) part_ms[i] = ms[i];
     if (calls) *calls = h->part_calls;
     return WN_OK;
@@ -1115,12 +1137,14 @@ extern "C" int wn_profile_parts_end(wn_handle* h, double* part_ms, int64_t* call
 
 extern "C" int wn_profile_pause(wn_handle* h, int paused) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_pause: null handle");
+    WN_SWITCH(h, "wn_profile_pause");
     h->prof_on = !paused;
     return WN_OK;
 }
 
 extern "C" int wn_profile_end(wn_handle* h, double* layer_ms, int64_t* layer_launches) {
     if (!h) return wn_fail(nullptr, WN_EINVAL, "wn_profile_end: null handle");
+    WN_SWITCH(h, "wn_profile_end");
     h->prof_on = false;
     double ms = 0.0;
     for (size_t i = 0; i + 1 < h->prof_events.size(); i += 2) {

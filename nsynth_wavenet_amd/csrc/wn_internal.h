@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -153,11 +155,17 @@ struct wn_handle {
     // resolved once in wn_create: WN_COND override of cond_mode 0 and the workspace limit of the hoisted form
     int cond_env_mode = 0;                    // WN_COND_AUTO or the form named by the environment
     bool dc_no_pg = false;                    // WN_DC_NO_PG=1 at wn_create: upsampler without the phase-group kernel (wn_deconv.hip)
-    int groups_env = 0;                       // WN_GROUPS=1 -> +1 (always), WN_NO_GROUPS=1 -> -1 (never), else 0 (policy)
+    int groups_env = 0;                       // launch structure in force: +1 groups always, -1 never, 0 size policy (wn_iaf_set_groups)
+    int groups_env0 = 0;                      // ... as wn_create resolved it (WN_GROUPS=1 / WN_NO_GROUPS=1): what mode 0 restores
     double hoist_limit_bytes = 96e9;          // a third of the device memory
-    mutable std::string err;
-    // cached hipGraph for the AR step (wn_ar.hip)
-    void* ar_graph_cache = nullptr;
+    // Work calls (generate / deconv / AR / teacher) hold `sw` SHARED while they are inside the library and read every switch
+    // once at their entry; the switches (wn_iaf_set_groups, wn_ar_set_graph, wn_profile_*) try to take it EXCLUSIVELY and
+    // return WN_ESTATE when a work call of another thread is in flight (wnhip.h, "Concurrency").
+    mutable std::shared_mutex sw;
+    std::mutex list_mu;                       // the event lists of the measurement modes and the AR graph list below
+    // hipGraphs of the wn_ar_generate calls in flight (wn_ar.hip): one entry per call, retired by later calls once its
+    // stream has run it, all released in wn_destroy
+    std::vector<void*> ar_graphs;
     bool ar_use_graph = true;                 // wn_ar_set_graph
     // bench.py measurement aid (wn_profile_begin/end)
     bool prof_on = false;
@@ -173,7 +181,17 @@ struct wn_handle {
 };
 
 // ---- error helpers ----
-int wn_fail(const wn_handle* h, int code, const char* fmt, ...);
+int wn_fail(const wn_handle* h, int code, const char* fmt, ...);   // message -> the calling thread's wn_last_error
+// a work call is inside the library (shared) / a switch changes the handle (exclusive, refused while busy)
+struct WnWork {
+    std::shared_lock<std::shared_mutex> lk;
+    explicit WnWork(const wn_handle* h) : lk(h->sw) {}
+};
+#define WN_SWITCH(h, fn)                                                                         \
+    std::unique_lock<std::shared_mutex> sw_lk__((h)->sw, std::try_to_lock);                      \
+    if (!sw_lk__.owns_lock())                                                                    \
+        return wn_fail((h), WN_ESTATE, fn ": a work call of another thread is in flight on this handle (switches are "  \
+                                          "refused while the handle is busy)")
 #define WN_HIP(h, expr)                                                              \
     do {                                                                             \
         hipError_t e__ = (expr);                                                     \

@@ -480,6 +480,7 @@ extern "C" int wn_teacher_forward(wn_handle* h, const float* wav, const float* m
     if (c.kind != WN_KIND_TEACHER) return wn_fail(h, WN_EINVAL, "wn_teacher_forward: handle is not a Wavenet teacher");
     if (B < 1 || F < 1 || T < 1 || !wav || !mel || !out_params || !ws)
         return wn_fail(h, WN_EINVAL, "wn_teacher_forward: bad argument");
+    const WnWork work(h);
     const long long TE = (long long)F * h->frame_shift, md = 1ll << (c.num_stages - 1);
     if (T > TE) return wn_fail(h, WN_EINVAL, "wn_teacher_forward: %lld samples need more than %d mel frames "
                                "(wavenet.py:79 assert cond_len >= x_len)", (long long)T, F);

@@ -250,7 +250,9 @@ class Engine(object):
 
     def set_layer_groups(self, mode):
         """Launch structure of the hoisted form: True / 1 = layer groups wherever they apply, False / -1 = one launch per
-        layer (pair), None / 0 = the library's size policy (wn_iaf_set_groups)."""
+        layer (pair), None / 0 = what the engine was created with: the library's size policy, or the form WN_GROUPS /
+        WN_NO_GROUPS named then (wn_iaf_set_groups).  A switch: raises RuntimeError (WN_ESTATE) while another thread's
+        generate call is inside the library."""
         m = 0 if mode is None else (1 if mode is True else -1 if mode is False else int(mode))
         self._check(self.lib.wn_iaf_set_groups(self._h, m))
         return self
@@ -274,7 +276,8 @@ class Engine(object):
         self._check(self.lib.wn_profile_parts_begin(self._h))
 
     def profile_parts_only(self, mask):
-        """Power measurements only: run just the parts whose bits are set (bit k = PROFILE_PARTS[k]; 15 = everything)."""
+        """Power measurements only, and only between profile_parts_begin() and profile_parts_end() (which disarms it): run
+        just the parts whose bits are set (bit k = PROFILE_PARTS[k]; 15 = everything)."""
         self._check(self.lib.wn_profile_parts_only(self._h, int(mask)))
 
     def profile_parts_end(self):

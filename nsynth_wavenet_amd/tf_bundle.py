@@ -59,9 +59,9 @@ def _native_crc():
             import ctypes
             from . import _lib
             lib = ctypes.CDLL(_lib.LIB_PATH)
-            lib.wnx_crc32c.restype = ctypes.c_uint32
-            lib.wnx_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
-            _native = lib.wnx_crc32c
+            lib.wn_crc32c.restype = ctypes.c_uint32
+            lib.wn_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+            _native = lib.wn_crc32c
         except (OSError, AttributeError):
             pass
     return _native

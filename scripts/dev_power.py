@@ -62,6 +62,9 @@ for i in range(20):
     eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
 torch.cuda.synchronize()
 rows = []
+# wn_profile_parts_only is accepted only inside a parts session (it makes a call SKIP work and cannot be left armed); the
+# session keeps at most 4096 part events, so the event bubbles end inside the first warm-up second
+eng.profile_parts_begin()
 for tag, mask in (('all', 15), ('upsampler', 2), ('cond_gemm', 4), ('residual_stack', 8), ('prologue_epilogue', 1), ('all_again', 15)):
     eng.profile_parts_only(15)
     for i in range(3):
@@ -90,7 +93,7 @@ for tag, mask in (('all', 15), ('upsampler', 2), ('cond_gemm', 4), ('residual_st
     us = dt / n * 1e6
     rows.append((tag, us, P, Fq, P * us * 1e-6))
     print('{:18s} {:9.1f} us/call  {:7.1f} W  {:6.0f} MHz  {:7.4f} J/call   ({} samples)'.format(tag, us, P, Fq, P * us * 1e-6, len(s.p)), flush=True)
-eng.profile_parts_only(15)
+eng.profile_parts_end()
 tot = sum(r[4] for r in rows if r[0] in ('upsampler', 'cond_gemm', 'residual_stack', 'prologue_epilogue'))
 print('sum of the parts: {:.4f} J, {:.1f} us; whole call: {:.4f} J, {:.1f} us'.format(
     tot, sum(r[1] for r in rows if r[0] in ('upsampler', 'cond_gemm', 'residual_stack', 'prologue_epilogue')), rows[0][4], rows[0][1]))

@@ -441,7 +441,8 @@ def test_phase_group_upsampler_matches_the_phase_major_form(monkeypatch):
 def test_part_timing_aid_accounts_for_the_call_and_leaves_results_alone():
     """wn_profile_parts_*: HIP events where the parts of a generate call begin (bench.py's in-process kernel_us_per_call).  The
     four parts of the default form are all present, non-negative and add up to about the wall time of the calls; the
-    recording does not change results; wn_profile_parts_only validates its mask and a restricted call still returns."""
+    recording does not change results; wn_profile_parts_only validates its mask, is refused outside a measurement session and
+    is disarmed by wn_profile_parts_end."""
     import time
     import torch
     from oracle import wavenet_np as O
@@ -469,9 +470,15 @@ def test_part_timing_aid_accounts_for_the_call_and_leaves_results_alone():
         eng.profile_parts_only(0)
     with pytest.raises(ValueError):
         eng.profile_parts_only(16)
+    # a restricted call SKIPS WORK, so the switch exists only inside a measurement session and cannot be left armed:
+    # refused outside one, disarmed by parts_end without the caller's help
+    with pytest.raises(RuntimeError, match='WN_ESTATE'):
+        eng.profile_parts_only(4)
+    assert torch.equal(eng.iaf_generate(mel, None, seed=5, want=('x',))['x'], ref)
+    eng.profile_parts_begin()
     eng.profile_parts_only(4)                               # conditioning GEMM alone (power measurements)
     eng.iaf_generate(mel, None, seed=5, want=('wav',), check_range=False)
-    eng.profile_parts_only(15)
+    eng.profile_parts_end()                                 # ... never reset to 15 by the caller
     assert torch.equal(eng.iaf_generate(mel, None, seed=5, want=('x',))['x'], ref)
     eng.close()
 

@@ -24,14 +24,23 @@ REFERENCE_STYLE_STUDENT = {
 
 
 def test_library_is_built_and_exports_every_declared_symbol():
+    """The C ABI is the boundary: what include/wnhip.h declares (WN_API) and the library's dynamic symbol table are the SAME
+    set -- nothing declared is missing, and no internal C++ helper, STL instantiation or per-unit marker leaks out
+    (libwnhip.so is linked with -fvisibility=hidden and a version script, nsynth_wavenet_amd/build.py)."""
+    import subprocess
     header = open(os.path.join(ROOT, 'include', 'wnhip.h')).read()
-    declared = sorted(set(re.findall(r'\b(wn_[a-z_0-9]+)\s*\(', header)))
+    declared = sorted(set(re.findall(r'^WN_API [^;(]*?\b(wn_[a-z_0-9]+)\s*\(', header, re.M)))
+    assert declared == sorted(set(re.findall(r'\b(wn_[a-z_0-9]+)\s*\(', header))), 'a declaration without WN_API'
     assert 'wn_iaf_generate' in declared and 'wn_ar_generate' in declared and len(declared) >= 17
     assert os.path.exists(_lib.LIB_PATH), 'run python -m nsynth_wavenet_amd.build'
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared:
         assert hasattr(lib, sym), sym
     assert sorted(_lib.SYMBOLS) == declared
+    nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in nm.splitlines() if ln.strip())
+    assert exported == declared, ('exported but not declared: {}; declared but not exported: {}'.format(
+        sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported))))
     assert _lib.load().wn_abi_version() == 1
 
 
