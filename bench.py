@@ -256,8 +256,33 @@ def clock_hz_of(clocks):
         return None
 
 
-def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp=0):
-    """`ramp` + W untimed steps, then K timed steps between barrier + synchronize fences; MAX over ranks."""
+def settle_clocks(step, cap_s=0.3, tol=0.005, batch=10):
+    """Untimed calls until the GPU has left its idle clocks: batches of `batch` calls, each closed by a synchronize, until
+    the means of two consecutive batches agree within `tol` (0.5 %), at most `cap_s` seconds.  From an idle GPU the first
+    ten calls take 1.3-1.6 ms, calls 11-20 1.21 ms, calls 21-50 1.13-1.16 ms, then 1.155 ms steady
+    (profiles/r05_clock_ramp.txt): a 5 + 20-step protocol started cold times that DVFS transient, 6 % below the kernels'
+    own rate on every box.  This is clock warm-up, not skipped work -- every timed step still runs the whole call --
+    and the line says how many calls it took (`ramp_steps`) and why it stopped (`ramp_reason`)."""
+    t_start = time.perf_counter()
+    prev, n = None, 0
+    while True:
+        t0 = time.perf_counter()
+        for i in range(batch):
+            step(200000 + n + i)
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        n += batch
+        mean = (now - t0) / batch
+        if prev is not None and abs(mean - prev) <= tol * prev:
+            return n, 'settled: two consecutive {}-call means within {:.1f} % ({:.4f} / {:.4f} ms)'.format(batch, tol * 100, prev * 1e3, mean * 1e3)
+        if now - t_start >= cap_s:
+            return n, 'cap of {:.1f} s reached (last {}-call means {:.4f} / {:.4f} ms)'.format(cap_s, batch, (prev or mean) * 1e3, mean * 1e3)
+        prev = mean
+
+
+def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp=-1):
+    """Clock settle (or `ramp` fixed extra steps) + W untimed steps, then K timed steps between barrier + synchronize
+    fences; MAX over ranks."""
     def step(i):
         # asynchronous calls: the fp16 range guard accumulates in the workspace and is read ONCE behind the timed
         # region (eng.check_range() in main: raises if any of these calls overflowed); a per-call read-back would put a
@@ -270,10 +295,13 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
             dist.barrier(**BARRIER_KW)
             torch.cuda.synchronize(dev)
 
-    # --ramp-steps N (default 0): extra untimed steps before the W the command asked for -- a 20-step run after 3
-    # warm-up steps catches the GPU still ramping its clocks (1.551 vs 1.508 ms per step on one box); off unless asked
-    for i in range(ramp):
-        step(100000 + i)
+    # --ramp-steps: -1 (default) = settle_clocks() above; N >= 0 = exactly N extra untimed steps (0: the bare protocol)
+    if ramp < 0:
+        ramp_n, ramp_why = settle_clocks(step)
+    else:
+        for i in range(ramp):
+            step(100000 + i)
+        ramp_n, ramp_why = ramp, 'fixed by --ramp-steps'
     for i in range(warmup):
         step(i)
     fence()
@@ -293,7 +321,7 @@ def measure(eng, mel, steps, warmup, rank, world, local, dev, events_every, ramp
         tt = torch.tensor([elapsed], dtype=torch.float64, device=RED_DEV or dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    return elapsed, layer_ms, layer_launches, wav
+    return elapsed, layer_ms, layer_launches, wav, (ramp_n, ramp_why)
 
 
 def three_fracs(alg_flop, moved_bytes, seconds, mfma_per_product=3, peak_tf=PEAK_F16_MFMA_TFLOPS):
@@ -605,8 +633,9 @@ def main():
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     ap.add_argument('--ar-samples', type=int, default=1600,
                     help='extras: generated samples per utterance of the autoregressive runs (configs[3]; 1600 = 0.1 s)')
-    ap.add_argument('--ramp-steps', type=int, default=0,
-                    help='extra untimed steps before the --warmup steps (clock ramp); 0 = exactly the protocol asked for')
+    ap.add_argument('--ramp-steps', type=int, default=-1,
+                    help='untimed steps before the --warmup steps: -1 (default) = until two consecutive 10-call means agree within '
+                         '0.5 %% (at most 0.3 s: the GPU leaves its idle clocks); N >= 0 = exactly N (0 = the bare protocol)')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--same-gpu', action='store_true', help=argparse.SUPPRESS)   # N ranks on GPU 0 over gloo: code-path check on a one-GPU box
     args = ap.parse_args()
@@ -643,8 +672,8 @@ def main():
     mel_host = np.random.RandomState(12345 + rank).uniform(0, 1, [B, F, 80]).astype(np.float32)
     mel = torch.from_numpy(mel_host).to(dev)
     clocks_before = gpu_clocks(local) if rank == 0 else None
-    elapsed, layer_ms, layer_launches, wav = measure(eng, mel, args.steps, args.warmup, rank, world, local, dev,
-                                                     args.layer_events_every, ramp=args.ramp_steps)
+    elapsed, layer_ms, layer_launches, wav, ramp_info = measure(eng, mel, args.steps, args.warmup, rank, world, local, dev,
+                                                                args.layer_events_every, ramp=args.ramp_steps)
     clocks_after = gpu_clocks(local) if rank == 0 else None
     assert wav.shape == (B, T) and bool(torch.isfinite(wav).all())
     eng.check_range()                     # raises if a split-fp16 operand left the fp16 range during the timed calls
@@ -676,7 +705,8 @@ def main():
             'world_size_seen': seen,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ramp_steps': args.ramp_steps,       # extra untimed steps before the warm-up steps (0 unless --ramp-steps)
+            'ramp_steps': ramp_info[0],          # untimed calls before the warm-up steps: clock settle (bench.py: settle_clocks)
+            'ramp_reason': ramp_info[1],
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
@@ -739,7 +769,7 @@ def main():
         if B != 8:
             mel8 = torch.from_numpy(np.random.RandomState(777).uniform(0, 1, [8, F, 80]).astype(np.float32)).to(dev)
             n8 = max(3, min(args.steps, 20))
-            el8, lms8, ll8, wav8 = measure(eng, mel8, n8, 2, rank, world, local, dev, 2)
+            el8, lms8, ll8, wav8, _ = measure(eng, mel8, n8, 2, rank, world, local, dev, 2)
             eng.check_range()
             r8 = roofline_of(eng, 8, F, T, lms8, ll8, clock_hz_of(clocks_after))
             r8.update({'batch_per_gpu': 8, 'steps': n8, 'ms_per_step': el8 / n8 * 1e3,
@@ -750,7 +780,7 @@ def main():
         if eng.precision != 'f32':
             eng32 = Engine(hp, kind='student', device=dev, precision='f32').load_weights(weights)
             n32 = max(3, min(args.steps, 20))
-            el32, lms32, ll32, wav32 = measure(eng32, mel, n32, 2, rank, world, local, dev, 2)
+            el32, lms32, ll32, wav32, _ = measure(eng32, mel, n32, 2, rank, world, local, dev, 2)
             assert bool(torch.isfinite(wav32).all())
             r32 = roofline_of(eng32, B, F, T, lms32, ll32, clock_hz_of(clocks_after))
             path_tf = PATH_FLOP_PER_SAMPLE * B * T * n32 / el32 / 1e12
@@ -764,7 +794,7 @@ def main():
         # aggregate = all ranks' samples over that time.  Weak scaling like the headline figure.
         def share(engine, nb, seed, steps):
             melb = torch.from_numpy(np.random.RandomState(seed + rank).uniform(0, 1, [nb, F, 80]).astype(np.float32)).to(dev)
-            el, _, _, w = measure(engine, melb, steps, 2, rank, world, local, dev, 1 << 30)
+            el, _, _, w, _ = measure(engine, melb, steps, 2, rank, world, local, dev, 1 << 30)
             engine.check_range()          # the timed calls are asynchronous: one question behind them (raises on overflow)
             assert w.shape == (nb, T) and bool(torch.isfinite(w).all())
             return {'batch_per_gpu': nb, 'utterances': nb * world, 'steps': steps, 'ms_per_step': el / steps * 1e3,

@@ -311,7 +311,14 @@ WN_API int wn_teacher_forward(wn_handle* h, const float* wav, const float* mel, 
  * (wavenet/loss_func.py:22-63), gauss_log_prob (:104-119) or the negated cross entropy of ce_loss (:128-133), by the
  * handle's loss_type, on the targets `Wavenet.encode_signal` derives from the raw audio (wavenet.py:157-178: mu-law / 128
  * and the class index when use_mu_law, the audio itself otherwise).  log_prob [B,T]; the reference's scalar loss is
- * minus its mean.  Asynchronous on `stream`; no workspace. */
+ * minus its mean.  Asynchronous on `stream`; no workspace.
+ * Accuracy contract (what "parity" means here): the values are the float64-accurate ones of the reference's FORMULAS.  The
+ * mixture-of-logistics bin mass is formed as sigma(a) sigma(-b) (1 - e^-(a-b)) with a - b computed directly; the reference's
+ * float32 graph evaluates sigmoid(plus) - sigmoid(min), which keeps about two digits of a mass of 1/65 536 -- a loss printed
+ * by a float32 TensorFlow run of the reference can therefore differ from this one in its third digit, by the reference's own
+ * cancellation, not by this path's error (tests hold 2e-5 against the float64 evaluation of the reference's code).  The
+ * mu-law class of a sample closer than ~1e-5 of a bin to a bin edge is decided by the rounding of a float32 log in any
+ * implementation; 1e-3 of a bin away from every edge the class is exact (tests/test_gpu_teacher.py). */
 WN_API int wn_teacher_log_prob(wn_handle* h, const float* out_params, const float* wav, int B, int64_t T, float* log_prob,
                         void* stream);
 

@@ -73,7 +73,7 @@ def audit_objects(objs, verbose=True):
     from . import hazard_audit
     findings = []
     for o in objs:
-        bad = hazard_audit.audit_object(o)
+        bad = hazard_audit.audit_object(o, allow_no_kernels=os.path.basename(o).startswith('wn_host'))
         if verbose:
             print('hazard audit %-18s %d finding(s)' % (os.path.basename(o), len(bad)), flush=True)
         findings += [(os.path.basename(o),) + tuple(b) for b in bad]

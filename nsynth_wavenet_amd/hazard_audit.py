@@ -132,29 +132,60 @@ def llvm_tool(name):
     raise RuntimeError(name + ' not found (set WN_LLVM_BIN)')
 
 
-def disassemble_object(obj, workdir):
-    """Device code of a hipcc object (offload bundle) or of a bare amdgcn ELF -> path of its llvm-objdump -d listing."""
+def disassemble_object(obj, workdir, allow_no_kernels=False):
+    """Device code of a hipcc object (offload bundle) or of a bare amdgcn ELF -> path of its llvm-objdump -d listing.
+
+    FAILS CLOSED: the listing handed to the audit must be that of a gfx950 device image and must contain kernel code.
+    A bundle llvm-objdump cannot unpack, a changed image naming, or an object with no device image at all would otherwise
+    be "audited" as the host object inside -- which has no gfx950 instruction and therefore no finding, exactly like a clean
+    device object -- and build() would link a library whose device code nobody looked at.  `allow_no_kernels` is for the
+    one object that really has no kernel (wn_host.o)."""
     import shutil
     objdump = llvm_tool('llvm-objdump')
     local = os.path.join(workdir, os.path.basename(obj))
     shutil.copy(obj, local)
-    subprocess.run([objdump, '--offloading', local], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    dev = [f for f in os.listdir(workdir) if f.startswith(os.path.basename(obj) + '.') and 'amdgcn' in f]
-    target = os.path.join(workdir, dev[0]) if dev else local        # no bundle inside: the file is the device ELF itself
+    with open(local, 'rb') as f:
+        head = f.read(20)
+    is_amdgcn_elf = head[:4] == b'\x7fELF' and head[18:20] == (224).to_bytes(2, 'little')     # e_machine EM_AMDGPU
+    if is_amdgcn_elf:
+        target = local                                                  # a bare device ELF (the crafted test objects)
+    else:
+        r = subprocess.run([objdump, '--offloading', local], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('llvm-objdump --offloading failed on {} (exit {}): {}'.format(obj, r.returncode, r.stderr.strip()))
+        dev = sorted(f for f in os.listdir(workdir) if f.startswith(os.path.basename(obj) + '.') and 'amdgcn' in f and 'gfx950' in f)
+        if not dev and allow_no_kernels:
+            # the host-only unit: acceptable only if the object really carries no offload bundle
+            sec = subprocess.run([objdump, '-h', local], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if sec.returncode == 0 and '.hip_fatbin' not in sec.stdout:
+                return None
+        if not dev:
+            raise RuntimeError('hazard audit: no gfx950 device image could be extracted from {} (llvm-objdump --offloading '
+                               'produced {}); refusing to audit the host object in its place'.format(
+                                   obj, sorted(os.listdir(workdir))))
+        target = os.path.join(workdir, dev[0])
     out = local + '.dis'
     with open(out, 'w') as f:
         r = subprocess.run([objdump, '-d', target], stdout=f, stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         raise RuntimeError('llvm-objdump failed on {}: {}'.format(obj, r.stderr))
+    with open(out) as f:
+        listing = f.read()
+    if 'elf64-amdgpu' not in listing:
+        raise RuntimeError('hazard audit: the listing of {} is not an AMDGPU disassembly'.format(obj))
+    if 's_endpgm' not in listing and not allow_no_kernels:
+        raise RuntimeError('hazard audit: the device image of {} contains no kernel code (no s_endpgm): nothing was audited'.format(obj))
     return out
 
 
-def audit_object(obj):
-    """Findings in the device code of one built object.  An object without gfx950 instructions (wn_host.o) has none."""
+def audit_object(obj, allow_no_kernels=False):
+    """Findings in the device code of one built object; raises when no gfx950 kernel code could be extracted from it
+    (allow_no_kernels: the host-only translation unit)."""
     import shutil
     tmp = tempfile.mkdtemp(prefix='wn_audit_obj_')
     try:
-        return audit(disassemble_object(obj, tmp), every_valu=True)
+        listing = disassemble_object(obj, tmp, allow_no_kernels)
+        return audit(listing, every_valu=True) if listing else []
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -57,13 +57,30 @@ class Wavenet(_TeacherBase):
         in the reference layout by this call)."""
         if init:
             raise ValueError('data-dependent initialisation is a training-time feature')
-        return {'out_params': self.engine.teacher_forward(inputs['wav'], inputs['mel'])}
+        # 'wav' is passed through so that the reference's own call sequence (train_wavenet.py:104-108, tests/test_wavenet.py:38-42:
+        # ff_dict = feed_forward(inputs); ff_dict.update(encode_signal(inputs)); calculate_loss(ff_dict)) runs unchanged
+        return {'out_params': self.engine.teacher_forward(inputs['wav'], inputs['mel']), 'wav': inputs['wav']}
 
     def calculate_loss(self, ff_dict):
-        """wavenet.py:293-316 for scoring audio under the teacher: ff_dict holds 'out_params' (feed_forward) and 'wav' (the raw
-        audio; the reference passes encode_signal's 'real_targets' / 'cate_targets', derived from it -- here the device derives
-        them).  Returns {'loss': -mean log-likelihood, 'log_probs': [B,T]}."""
-        lp = self.engine.teacher_log_prob(ff_dict['out_params'], ff_dict['wav'])
+        """wavenet.py:293-316 for scoring audio under the teacher.  ff_dict holds 'out_params' (feed_forward) and the audio: the
+        raw 'wav' (feed_forward passes it through; the device derives the targets of encode_signal from it), or -- the reference's
+        own keys -- encode_signal's 'real_targets' / 'cate_targets' alone: without mu-law the real target IS the audio; with it
+        the class index is handed back as the centre of its bin, inv_mu_law(i), which the device's mu_law maps to the same index
+        and the same real target i / 128 (the codec round trip of SURVEY K7, tests/test_ref_codec.py).
+        Returns {'loss': -mean log-likelihood, 'log_probs': [B,T]}.  The mixture-of-logistics score is the float64-accurate
+        value of the bin mass, not the float32 difference of two sigmoids TensorFlow evaluates (include/wnhip.h)."""
+        if 'wav' in ff_dict:
+            wav = ff_dict['wav']
+        elif self.use_mu_law and 'cate_targets' in ff_dict:
+            from ..auxilaries import utils
+            cate = ff_dict['cate_targets']
+            cate = cate.cpu().numpy() if hasattr(cate, 'cpu') else np.asarray(cate)
+            wav = utils.inv_mu_law_numpy(cate.astype(np.int32) - self.quant_chann // 2).astype(np.float32)
+        elif not self.use_mu_law and 'real_targets' in ff_dict:
+            wav = ff_dict['real_targets']
+        else:
+            raise KeyError("calculate_loss needs 'wav', or encode_signal's 'real_targets' / 'cate_targets', beside 'out_params'")
+        lp = self.engine.teacher_log_prob(ff_dict['out_params'], wav)
         return {'loss': -lp.mean(), 'log_probs': lp}
 
 

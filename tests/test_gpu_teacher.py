@@ -93,3 +93,37 @@ def test_forward_with_fp32_upsampler_handle():
     out = _np(eng.teacher_forward(g['forced'], g['mel']))
     assert np.abs(out - g['out_forced']).max() <= 2e-5 * max(1.0, np.abs(g['out_forced']).max())
     eng.close()
+
+
+def test_scoring_picks_the_right_class_on_both_sides_of_every_mu_law_bin_edge():
+    """Teacher scoring with a cross-entropy head: the target class is mu_law(wav) + 128 (wavenet.py:157-178), and a one-bin
+    slip changes a sample's log-probability by O(1).  Audio is placed 1e-3 of a bin below and above each of the 255 interior
+    bin edges -- |x_e| = (256^(k/128) - 1) / 255 -- and at the bin centres: the device must score exactly the class the float64
+    definition gives.  (Closer than ~1e-5 of a bin to an edge the float32 `log` of ANY implementation -- this one, numpy's,
+    TensorFlow's -- decides the side; that band is not the reference's to pin either.)"""
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, 'ar_ce_mulaw.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    hp = O.HP(cfgd)
+    assert hp.use_mu_law and hp.loss_type == 'ce'
+    eng = Engine(cfgd).load_weights(O.synth_weights(hp, 'teacher', seed=1234, init='unit'))
+
+    def x_of(v):                                     # audio whose mu-law value (before floor) is v, v in (-128, 128)
+        return np.sign(v) * (np.exp(np.abs(v) / 128.0 * np.log(256.0)) - 1.0) / 255.0
+    k = np.arange(-127, 128, dtype=np.float64)       # the interior edges
+    k = k[k != 0]                                    # (sign(x) makes 0 an edge of its own kind: floor(+-0) = 0 both sides)
+    v = np.concatenate([k - 1e-3, k + 1e-3, np.arange(-128, 128) + 0.5])
+    want = np.floor(v).astype(np.int64) + 128
+    wav = x_of(v).astype(np.float32)[None, :]
+    assert np.array_equal(O.encode_targets(wav.astype(np.float64), hp, np.float64)[1][0], want)
+    rs = np.random.RandomState(5)
+    out = rs.normal(0, 3, [1, wav.shape[1], 256]).astype(np.float32)
+    lp = _np(eng.teacher_log_prob(out, wav))[0]
+    ref_all = out[0].astype(np.float64) - np.log(np.sum(np.exp(out[0].astype(np.float64)), axis=-1, keepdims=True))
+    ref = ref_all[np.arange(len(want)), want]
+    # the scored class is identifiable: the 256 logits of a sample are distinct to ~1e-2, the tolerance is 1e-4
+    got_class = np.argmin(np.abs(ref_all - lp[:, None]), axis=1)
+    assert np.array_equal(got_class, want), np.flatnonzero(got_class != want)[:10]
+    assert np.abs(lp - ref).max() <= 1e-4
+    eng.close()

@@ -120,6 +120,26 @@ def test_build_refuses_objects_that_contain_a_hazard(tmp_path):
     wnbuild.audit_objects(shipped, verbose=False)
     lst = hazard_audit.disassemble_object(os.path.join(wnbuild.LIB_DIR, 'wn_iaf_g.o'), str(tmp_path))
     assert open(lst).read().count('v_mfma_f32_16x16x32_f16') > 1000
+    # the gate FAILS CLOSED: an object from which no gfx950 kernel code can be extracted is an error, not "0 findings" --
+    # a host object (what a failed bundle extraction used to fall back to), a device ELF without a kernel, garbage
+    host_c = tmp_path / 'h.c'
+    host_c.write_text('int f(int x) { return x + 1; }\n')
+    host_o = tmp_path / 'host_only.o'
+    subprocess.run(['gcc', '-c', str(host_c), '-o', str(host_o)], check=True, capture_output=True)
+    with pytest.raises(RuntimeError, match='no gfx950 device image'):
+        hazard_audit.audit_object(str(host_o))
+    assert hazard_audit.audit_object(str(host_o), allow_no_kernels=True) == []          # (wn_host.o: no offload bundle inside)
+    empty_s = tmp_path / 'empty.s'
+    empty_s.write_text('\t.text\n\t.globl d\nd:\n\ts_nop 0\n')
+    empty_o = tmp_path / 'empty.o'
+    subprocess.run([clang, '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', str(empty_s), '-o', str(empty_o)],
+                   check=True, capture_output=True)
+    with pytest.raises(RuntimeError, match='no kernel code'):
+        hazard_audit.audit_object(str(empty_o))
+    junk = tmp_path / 'junk.o'
+    junk.write_bytes(b'not an object file at all')
+    with pytest.raises(RuntimeError):
+        hazard_audit.audit_object(str(junk))
 
 
 def test_mel_entry_points_validate_arguments_before_touching_a_device():

@@ -374,6 +374,11 @@ def test_oracle_teacher_scoring_equals_the_reference_code(R, tag):
     assert abs(-lp.mean() - float(R[tag + '/loss_f64'])) <= 1e-10 * max(1.0, abs(float(R[tag + '/loss_f64'])))
 
 
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', TEACHER_GOLD + TEACHER_EXTRA)
 def test_engine_teacher_scoring_against_the_reference_code(R, tag):
@@ -394,6 +399,16 @@ def test_engine_teacher_scoring_against_the_reference_code(R, tag):
     e2 = float(np.abs(_np(res['log_probs']) - ref).max())
     assert e2 <= 10 * tol, (tag, e2)
     assert abs(float(res['loss']) - float(R[tag + '/loss_f64'])) <= 2e-5 * max(1.0, abs(float(R[tag + '/loss_f64'])))
+    # the reference's own call sequence (train_wavenet.py:104-108, tests/test_wavenet.py:38-42) runs unchanged ...
+    inputs = {'wav': g['forced'], 'mel': g['mel']}
+    ff_dict = wn.feed_forward(inputs)
+    ff_dict.update(wn.encode_signal(inputs))
+    assert torch_equal(wn.calculate_loss(ff_dict)['log_probs'], res['log_probs'])
+    # ... and so does a dictionary that holds only the reference's keys (no raw 'wav')
+    ref_keys = {k: ff_dict[k] for k in ('out_params', 'real_targets', 'cate_targets')}
+    assert torch_equal(wn.calculate_loss(ref_keys)['log_probs'], res['log_probs'])
+    with pytest.raises(KeyError):
+        wn.calculate_loss({'out_params': ff['out_params']})
     from oracle import wavenet_np as O
     es = wn.encode_signal({'wav': g['forced']})
     real, cate = O.encode_targets(g['forced'], O.HP(cfgd), np.float32)
