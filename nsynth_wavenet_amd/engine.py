@@ -31,7 +31,9 @@ class Engine(object):
         self.kind = kind or cfg.model_kind(self.hp)
         self.device = torch.device(device if device is not None else 'cuda:{}'.format(torch.cuda.current_device()))
         self.n_mel = n_mel
-        self._h = ctypes.c_void_p(0)
+        self._hbox = [ctypes.c_void_p(0)]   # the C handle, shared with the engine's forks (fork())
+        self._shared = {'ar_graph': None}   # handle-wide switch states the forks must agree on
+        self._is_fork = False
         self._ws = None
         self._ar_stream = None
         self._last_ws = None
@@ -40,16 +42,39 @@ class Engine(object):
         self.precision = precision or cfg.default_precision()
         c = cfg.to_wn_config(self.hp, self.kind, n_mel, self.precision)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.wn_create(ctypes.byref(c), ctypes.byref(self._h)))
+            _lib.check(self.lib.wn_create(ctypes.byref(c), ctypes.byref(self._hbox[0])))
         self.quant_chann = cfg.quant_chann(self.hp)
         self.frame_shift = cfg.frame_shift(self.hp)
 
+    @property
+    def _h(self):
+        return self._hbox[0]
+
     # ---- lifecycle ----
     def close(self):
+        """Destroy the C handle (the owner) / drop this caller's workspace (a fork: the handle belongs to its parent)."""
+        self._ws = self._last_ws = None
+        if self._is_fork:
+            return
         if self._h:
             torch.cuda.synchronize(self.device)
             self.lib.wn_destroy(self._h)
-            self._h = ctypes.c_void_p(0)
+            self._hbox[0] = ctypes.c_void_p(0)
+
+    def fork(self):
+        """A second CALLER of the same C handle (SURVEY 8(b) "Threading / streams": a finalized handle is immutable and
+        may be shared by concurrent callers using distinct workspaces and streams): shares the packed weights on the
+        device, owns its workspace, and issues its work on the torch stream that is current in the calling thread
+        (`with torch.cuda.stream(s): fork.iaf_generate(...)`).  Forks are what host threads use -- one fork per thread;
+        an Engine object itself (one workspace) is not to be shared between threads.  The parent must outlive its forks."""
+        import copy
+        if not self._finalized:
+            raise RuntimeError('fork() needs a finalized engine (load_weights first)')
+        f = copy.copy(self)                 # same _hbox / _shared objects, same hparams
+        f._is_fork = True
+        f._ws = f._last_ws = f._ar_stream = None
+        f.range_fallbacks = 0
+        return f
 
     def __del__(self):
         try:
@@ -346,7 +371,15 @@ class Engine(object):
         out['mel_cond_out1'] = buf[NL * B * Tn * G:].view(B, Tn, S)
         return out
 
-    def ar_generate(self, enc, rnd=None, seed=0, forced_wav=None, want_out=False, use_graph=False):
+    def _set_ar_graph(self, on):
+        """wn_ar_set_graph is a SWITCH of the shared handle (refused while another caller's work call is in flight): flipped
+        only when the wanted state differs from the one the engine and its forks last set."""
+        on = bool(on)
+        if self._shared['ar_graph'] is not on:
+            self._check(self.lib.wn_ar_set_graph(self._h, 1 if on else 0))
+            self._shared['ar_graph'] = on
+
+    def ar_generate(self, enc, rnd=None, seed=0, forced_wav=None, want_out=False, use_graph=False, streams=1):
         """fastgen.synthesis loop.  enc [B,Tn,deconv_width], rnd [Tn,B,ar_n_rand()] or None (drawn on the
         device), forced_wav [B,Tn] or None -> dict(idx, wav[, out_params]).
         The loop is a static sequence of kernels per step (every per-step address is derived on the device).
@@ -354,7 +387,13 @@ class Engine(object):
         graph); a graph cannot be captured on the legacy null stream PyTorch uses by default, so that form runs
         on a side stream of its own, ordered after and joined back into the caller's current stream.  Measured
         on MI355X the two are equally fast (191 vs 193 us per step at one utterance: the dependent-kernel chain
-        on the GPU is the bound, not launch submission) and the capture costs ~20 ms per call, hence the default."""
+        on the GPU is the bound, not launch submission) and the capture costs ~20 ms per call, hence the default.
+
+        streams=G > 1: the batch is cut into G contiguous groups of utterances, each an independent chain with its own
+        queue state on its own stream, all against the one shared handle (utterances never interact: wavenet.py:379-514
+        has no cross-batch term, so the results are those of the single-stream call row for row).  A step is ~65
+        dependent launches of a few microseconds of work each and leaves the GPU idle in between; chains on other streams
+        fill those gaps.  Each group replays hipGraphs (cheap to enqueue from one host thread), whatever use_graph says."""
         enc = self._dev(enc)
         if enc.dim() != 3 or int(enc.shape[2]) != int(self.hp.deconv_width):
             raise ValueError('ar_generate: enc must be [batch, steps, {}], got {}'.format(self.hp.deconv_width, tuple(enc.shape)))
@@ -364,6 +403,11 @@ class Engine(object):
         forced = self._dev(forced_wav)
         if forced is not None and tuple(forced.shape) != (B, Tn):
             raise ValueError('ar_generate: forced_wav must be [{}, {}], got {}'.format(B, Tn, tuple(forced.shape)))
+        G = int(streams)
+        if G < 1 or G > B:
+            raise ValueError('ar_generate: streams must be in 1..batch ({}), got {}'.format(B, streams))
+        if G > 1:
+            return self._ar_generate_streams(enc, rnd, seed, forced, want_out, G)
         idx = torch.empty((B, Tn), dtype=torch.int32, device=self.device)
         wav = torch.empty((B, Tn), dtype=torch.float32, device=self.device)
         outp = torch.empty((B, Tn, cfg.teacher_out_width(self.hp)), dtype=torch.float32, device=self.device) \
@@ -372,7 +416,7 @@ class Engine(object):
             nb = self.lib.wn_ar_state_bytes(self._h, B)
             ws = self._workspace(nb)
             cur = torch.cuda.current_stream(self.device)
-            self._check(self.lib.wn_ar_set_graph(self._h, 1 if use_graph else 0))
+            self._set_ar_graph(use_graph)
             if use_graph:
                 if self._ar_stream is None:
                     self._ar_stream = torch.cuda.Stream(self.device)
@@ -388,4 +432,48 @@ class Engine(object):
         out = {'idx': idx, 'wav': wav}
         if want_out:
             out['out_params'] = outp
+        return out
+
+    def _ar_generate_streams(self, enc, rnd, seed, forced, want_out, G):
+        B, Tn = int(enc.shape[0]), int(enc.shape[1])
+        ow = cfg.teacher_out_width(self.hp)
+        if not hasattr(self, '_ar_groups') or self._ar_groups is None or len(self._ar_groups) < G:
+            self._ar_groups = [{'stream': torch.cuda.Stream(self.device), 'ws': None} for _ in range(G)]
+        bounds = [B * g // G for g in range(G + 1)]
+        parts = []
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            self._set_ar_graph(True)
+            for g in range(G):
+                lo, hi = bounds[g], bounds[g + 1]
+                nb_ = hi - lo
+                grp = self._ar_groups[g]
+                need = int(self.lib.wn_ar_state_bytes(self._h, nb_))
+                if grp['ws'] is None or grp['ws'].numel() < need:
+                    grp['ws'] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                # per-group inputs / outputs are contiguous tensors of their own (the C ABI takes dense [b, Tn, ...] arrays)
+                e = enc[lo:hi].contiguous()
+                r = rnd[:, lo:hi].contiguous() if rnd is not None else None
+                f = forced[lo:hi].contiguous() if forced is not None else None
+                idx = torch.empty((nb_, Tn), dtype=torch.int32, device=self.device)
+                wav = torch.empty((nb_, Tn), dtype=torch.float32, device=self.device)
+                outp = torch.empty((nb_, Tn, ow), dtype=torch.float32, device=self.device) if want_out else None
+                parts.append((e, r, f, idx, wav, outp))
+            for g in range(G):
+                self._ar_groups[g]['stream'].wait_stream(cur)
+            for g in range(G):
+                e, r, f, idx, wav, outp = parts[g]
+                grp = self._ar_groups[g]
+                # device-drawn randoms: every group draws from its own Philox key (seed + group); injected randoms are
+                # the caller's columns lo..hi, so the result is the single-stream call's row for row
+                self._check(self.lib.wn_ar_generate(
+                    self._h, _ptr(e), int(e.shape[0]), Tn, _ptr(r), ctypes.c_uint64(int(seed) + g), _ptr(idx), _ptr(wav),
+                    _ptr(f), _ptr(outp), _ptr(grp['ws']), grp['ws'].numel(), ctypes.c_void_p(grp['stream'].cuda_stream)))
+            for g in range(G):
+                cur.wait_stream(self._ar_groups[g]['stream'])
+            # (every tensor above was allocated on `cur`, the side streams start behind it and are joined back into it:
+            # the caching allocator can only hand their memory to work that `cur` orders behind the joins)
+        out = {'idx': torch.cat([p[3] for p in parts], 0), 'wav': torch.cat([p[4] for p in parts], 0)}
+        if want_out:
+            out['out_params'] = torch.cat([p[5] for p in parts], 0)
         return out

@@ -7,9 +7,11 @@
   configs[4]  parallel_wavenet_gauss.json as shipped (Gaussian head, four PRIVATE deconv stacks), the
               per-GPU share of 128 utterances over 8 GPUs = 16 utterances of F = 384.
 
-The waveform is synthetic (the reference's test wav is not copied into this repository); everything
-else -- featuriser on the device, upsampler, flows / autoregressive loop, quantiser -- is the product path
-through the C ABI.  Checked: the reference-held facts (lengths, 2^-15 grid, range), the reference's
+configs[0] runs on the mel of the reference's ACTUAL test utterance: tests/golden/fixture_mel.npz holds the [773, 80]
+mel of /root/reference/tests/test_data/test.wav, computed in the build container by tests/golden/make_fixture_mel.py with
+this repository's featuriser (data; the wav itself is not copied -- only its first 2 048 samples, the teacher-forced prefix of
+the K1 check).  The device featuriser is exercised on a synthetic utterance of the same length.  Everything else --
+upsampler, flows / autoregressive loop, quantiser -- is the product path through the C ABI.  Checked: the reference-held facts (lengths, 2^-15 grid, range), the reference's
 invariants K1 / K2, and parity with the CPU restatements where they finish in seconds."""
 import os
 
@@ -36,9 +38,18 @@ def _fixture_shaped_wav():
     return np.clip(y, -0.99, 0.99).astype(np.float32)[None, :]
 
 
-def test_config0_student_on_the_fixture_shaped_utterance():
-    """wav -> device mel (F = 773) -> IAF: 154 112 samples with centre crop 244 (K4), K2, K5, both execution
-    forms, and parity with the independent torch-CPU implementation on the whole utterance."""
+def _fixture_mel():
+    """([1, 773, 80] mel of the reference's tests/test_data/test.wav, its first 2 048 samples [1, 2048])."""
+    fx = np.load(os.path.join(GOLD, 'fixture_mel.npz'))
+    facts = np.load(os.path.join(GOLD, 'ref_fixture_facts.npz'))
+    assert fx['mel'].shape == (773, 80) and int(fx['n_samples']) == int(facts['test_wav/n']) == 154480
+    return fx['mel'][None].astype(np.float32), fx['wav_head'][None].astype(np.float32)
+
+
+def test_config0_student_on_the_reference_fixture_mel():
+    """The mel of the reference's own test utterance (F = 773) -> IAF: 154 112 samples with centre crop 244 (K4), K2,
+    K5, both execution forms, and parity with the independent torch-CPU implementation on the whole utterance; the
+    device featuriser gives the same frame count for an utterance of that length."""
     import torch
     from oracle import wavenet_np as O
     from oracle.torch_ref import StudentRef
@@ -46,8 +57,9 @@ def test_config0_student_on_the_fixture_shaped_utterance():
     from nsynth_wavenet_amd.engine import Engine
     facts = np.load(os.path.join(GOLD, 'ref_fixture_facts.npz'))
     wav_in = _fixture_shaped_wav()
-    mel = M.batch_melspectrogram_device(wav_in)
-    assert mel.is_cuda and tuple(mel.shape) == (1, 773, 80)
+    mel_dev = M.batch_melspectrogram_device(wav_in)
+    assert mel_dev.is_cuda and tuple(mel_dev.shape) == (1, 773, 80)
+    mel = torch.from_numpy(_fixture_mel()[0]).cuda()
     cfgd = load_json('parallel_wavenet.json')
     hp = O.HP(cfgd)
     w = O.synth_weights(hp, 'student', seed=1234, init='tf')
@@ -111,15 +123,16 @@ def test_layer_groups_at_two_and_three_full_size_utterances(batch):
     eng.close()
 
 
-def test_config0_fastgen_on_the_fixture_shaped_utterance():
-    """wavenet_mol.json as shipped: wav -> device mel -> fastgen.encode (F*200 = 154 600 conditioning steps),
+def test_config0_fastgen_on_the_reference_fixture_mel():
+    """wavenet_mol.json as shipped on the mel of the reference's own test utterance: fastgen.encode (F*200 = 154 600 conditioning steps),
     K1 on a 2 048-step prefix (incremental step == full-sequence teacher == float64 oracle), then the free-running
     loop over ALL 154 600 steps: length, 2^-15 grid and range of the reference's gen_LJ001-0001.wav (K4, K5)."""
     from oracle import wavenet_np as O
     from nsynth_wavenet_amd.auxilaries import mel_extractor as M
     from nsynth_wavenet_amd.engine import Engine
-    wav_in = _fixture_shaped_wav()
-    mel = M.batch_melspectrogram_device(wav_in)
+    import torch
+    mel_np, wav_head = _fixture_mel()
+    mel = torch.from_numpy(mel_np).cuda()
     cfgd = load_json('wavenet_mol.json')
     hp = O.HP(cfgd)
     w = O.synth_weights(hp, 'teacher', seed=1234, init='unit')
@@ -134,7 +147,7 @@ def test_config0_fastgen_on_the_fixture_shaped_utterance():
     left = (Fp * 200 - P) // 2
     mel_p = mel[:, :Fp]
     enc_p = _np(eng.deconv(mel_p))[:, left:left + P]
-    forced = wav_in[:, :P]
+    forced = wav_head[:, :P]                       # the utterance's own first 2 048 samples
     rnd = np.random.RandomState(777).uniform(1e-5, 1 - 1e-5, [P, 1, eng.ar_n_rand()]).astype(np.float32)
     inc = _np(eng.ar_generate(enc_p, rnd, forced_wav=forced, want_out=True)['out_params'])
     full = _np(eng.teacher_forward(forced, mel_p))

@@ -2,6 +2,8 @@
 (oracle/mel_np.py, float64, explicit DFT, no shared code) are EACH held against closed-form analysis -- two
 stationary tones and a unit impulse -- and against each other on noise.  The GPU twin of this test is
 tests/test_gpu_iaf.py::test_device_mel_featuriser_against_analysis."""
+import os
+
 import numpy as np
 
 from nsynth_wavenet_amd.auxilaries import mel_extractor as M
@@ -63,3 +65,23 @@ def test_host_featuriser_matches_the_oracle_on_noise_and_the_fixture_length():
     assert a.shape == b.shape == (31, 80)
     assert np.abs(a - b).max() < 5e-5
     assert M.melspectrogram(np.zeros(154480, np.float32)).shape == (773, 80)      # the reference fixture: 1 + 154480 // 200
+
+
+def test_fixture_mel_of_the_reference_test_utterance_is_well_formed():
+    """tests/golden/fixture_mel.npz (made by make_fixture_mel.py from the reference's tests/test_data/test.wav): F = 1 + n // 200
+    = 773 frames for the 154 480 samples the reference's fixture has, values on the featuriser's [40/140, 1] range
+    (auxilaries/mel_extractor.py:85-90: 20 log10(1e-5) = -100 dB is the floor), and the stored head of the utterance re-analysed
+    by the host featuriser AND by the float64 oracle reproduces the fixture's first frames (those whose window ends inside the head)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(here, 'golden', 'fixture_mel.npz'))
+    facts = np.load(os.path.join(here, 'golden', 'ref_fixture_facts.npz'))
+    mel, n = fx['mel'], int(fx['n_samples'])
+    assert n == int(facts['test_wav/n']) == 154480 and mel.shape == (1 + n // 200, 80) == (773, 80) and mel.dtype == np.float32
+    assert mel.min() >= 40.0 / 140.0 - 1e-6 and mel.max() <= 1.0 and mel.std() > 0.05
+    head = fx['wav_head']
+    assert head.shape == (2048,) and np.abs(head).max() <= 1.0
+    # frame f covers samples [200 f - 400, 200 f + 400) (a window of 800 centred in the 2 048-point frame): frames 0..8 lie
+    # inside the first 2 048 samples (frame 0 reaches into the reflect padding, which mirrors samples 1..400 of the head)
+    for fn in (M.melspectrogram, lambda y: np.asarray(OM.melspectrogram(y), np.float32)):
+        got = fn(head)[:9]
+        assert np.abs(got - mel[:9]).max() <= 2e-5, float(np.abs(got - mel[:9]).max())
