@@ -58,7 +58,7 @@ PEAK_HBM_GBPS = 8000.0
 SUSTAINED_F16_MFMA_TFLOPS = 1657.0
 BARRIER_KW = {}
 RED_DEV = None
-PROFILE_ROUND = 'r05'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
+PROFILE_ROUND = 'r06'                  # profiles/<round>_pmc_summary_*.json hold the PMC passes of this round's kernels
 DOMINANT_KERNEL = 'iaf_group_kernel'    # layer groups at one / two utterances; 'iaf_layer_c_kernel' when every layer is a launch
 GROUP_LAYERS = 5                       # residual layers per launch of the group kernel (one half of a dilation cycle)
 # One 16-sample block of one residual layer on a gfx950 SIMD: 84 x v_mfma_f32_16x16x32_f16 = 1344 cycles of the matrix
@@ -78,7 +78,9 @@ def pmc_replay(B, F, precision='f16x3', hoisted=False, kernel=None):
     process runs: a summary carries the hash of csrc/ + include/ (build.source_hash) it was measured
     on; a summary without a hash, or with another one, is stale and gives None."""
     none = {'traffic': None, 'mfma_util': None, 'kernel_us_per_call': None, 'file': None}
-    if precision == 'f32':
+    if precision in ('f32', 'f32-hoisted') and hoisted:
+        names, kernel = [PROFILE_ROUND + '_pmc_summary_f32.json'], kernel or 'iaf_layer_kernel<true>'
+    elif precision.startswith('f32'):
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
     elif precision in ('f16x3', 'f16x3-hoisted') and hoisted:
         names = [PROFILE_ROUND + '_pmc_summary_f16x3.json', PROFILE_ROUND + '_pmc_summary_f16x3_batch8.json']
@@ -343,7 +345,7 @@ def part_rooflines(eng, hp, B, F, T, part_us, pm):
     (HIP events at the part boundaries, wn_profile_parts_*), with traffic / mfma_util of the committed PMC pass when it was
     taken on these kernel sources."""
     out = {}
-    f32 = eng.precision == 'f32'
+    f32 = eng.precision.startswith('f32')
     npp, peak = (1, PEAK_F32_MFMA_TFLOPS) if f32 else (3, PEAK_F16_MFMA_TFLOPS)
     kern = pm.get('kernels') or {}
 
@@ -504,7 +506,22 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
     achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
     hoisted = eng.iaf_cond_hoisted(B, F)
     kernel_key = None
-    if hoisted and eng.iaf_layer_groups(B, F):
+    f32 = eng.precision.startswith('f32')
+    if f32 and hoisted:
+        # fp32 form, round 6: the conditioning 1x1s in one fp32 GEMM per deconv stack (gemm_f32_kernel, `roofline_cond`),
+        # the per-layer launch keeps the dilated conv, the gate and the residual 1x1 -- K = 192 + 32 instead of 448 + 32
+        kernel_key = 'iaf_layer_kernel<true>'
+        flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * B * T
+        bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
+        achieved_tf = flops_per_launch / avg_layer_s / 1e12
+        achieved_gbps = bytes_per_launch / avg_layer_s / 1e9
+        roof = {'kernel': 'iaf_layer_kernel<HOIST> (wn_iaf.hip: dilated conv + gate + residual 1x1 on the hoisted fp32 conditioning term, fp32 MFMA)',
+                'bound': 'mfma', 'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS},
+                'quantisation_note': 'one utterance = 4 800 blocks of 16 samples on 1 024 SIMDs = 4.69 per SIMD: a launch runs '
+                                     '5 rounds, 0.94 of the peak before any other loss'}
+    elif hoisted and eng.iaf_layer_groups(B, F):
         # Layer groups: one launch = GROUP_LAYERS residual layers of every sample, the residual stream in LDS; the event
         # pairs bracket every group launch of the call.  What binds the launch is the issue of a CU's SIMDs -- the matrix
         # pipe and, beside it, the VALU -- not HBM: `bound` = "mfma", `achieved` = the fp16 MFMA rate the launch executes
@@ -570,7 +587,6 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
                 'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS,
                 'hbm_view': {'algorithmic_GBps': achieved_gbps, 'peak_GBps': PEAK_HBM_GBPS}}
     pm = pmc_replay(B, F, eng.precision, hoisted, kernel_key)
-    f32 = eng.precision == 'f32'
     roof.update(three_fracs(flops_per_launch, bytes_per_launch, avg_layer_s, 1 if f32 else 3,
                             PEAK_F32_MFMA_TFLOPS if f32 else PEAK_F16_MFMA_TFLOPS))
     roof.update({'traffic': pm['traffic'], 'mfma_util': pm['mfma_util'], 'pmc_file': pm['file'],
@@ -629,7 +645,7 @@ def main():
                     help='skip everything behind the timed region: part timing, power sampling, the AR / teacher figures, the PCIe-inclusive call, the 8-utterance and fp32 blocks')
     ap.add_argument('--layer-events-every', type=int, default=20,
                     help='record the HIP-event pairs around the layer kernels in every n-th timed step')
-    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32'],
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'f16x3-fused', 'f16x3-hoisted', 'f32', 'f32-fused', 'f32-hoisted'],
                     help='IAF contraction arithmetic (default: f16x3 = split-fp16 on the fp16 MFMA)')
     ap.add_argument('--ar-samples', type=int, default=1600,
                     help='extras: generated samples per utterance of the autoregressive runs (configs[3]; 1600 = 0.1 s)')
@@ -694,7 +710,7 @@ def main():
         roof['path_8d_view'] = {'bytes_per_sample': PATH_BYTES_PER_SAMPLE, 'GBps': gbps, 'frac': gbps / 8000.0,
                                 'note': 'whole generate call, SURVEY 8(d) accounting (every layer reads l and enc and '
                                         'writes l once); the shipped launch structure moves fewer bytes than this model'}
-        dtype = 'f32' if eng.precision == 'f32' else \
+        dtype = 'f32' if eng.precision.startswith('f32') else \
             'split-fp16: activations stored as fp16 hi+lo pairs (32 bits per value, 22-bit significand, fp16 exponent ' \
             'range), contractions as 3 fp16 MFMAs per product with fp32 accumulate; conditioning term and outputs fp32'
         rec = {
@@ -777,7 +793,7 @@ def main():
             rec['roofline_b8'] = r8
         # (3) the same workload in the reference's own arithmetic: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the
         #     split-fp16 contraction -- driver-timed beside the headline figure
-        if eng.precision != 'f32':
+        if not eng.precision.startswith('f32'):
             eng32 = Engine(hp, kind='student', device=dev, precision='f32').load_weights(weights)
             n32 = max(3, min(args.steps, 20))
             el32, lms32, ll32, wav32, _ = measure(eng32, mel, n32, 2, rank, world, local, dev, 2)

@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--frames', type=int, default=384, help='teacher: mel frames (384 -> 76800 samples)')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--graph', action='store_true', help='AR: hipGraph replay instead of plain launches')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='AR: cut the batch into this many utterance groups, each an independent chain on its own stream (one shared handle)')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'wavenet_mol.json'))
     args = ap.parse_args()
     with open(args.config) as f:
@@ -47,11 +49,11 @@ def main():
     if args.workload == 'ar':
         Tn = args.samples
         enc = torch.as_tensor((rs.standard_normal([B, Tn, Cd]) * 0.1).astype(np.float32)).to(dev)
-        eng.ar_generate(enc, None, seed=1, use_graph=args.graph)
+        eng.ar_generate(enc, None, seed=1, use_graph=args.graph, streams=args.streams)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            out = eng.ar_generate(enc, None, seed=2 + i, use_graph=args.graph)
+            out = eng.ar_generate(enc, None, seed=2 + i, use_graph=args.graph, streams=args.streams)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / args.steps
         assert bool(torch.isfinite(out['wav']).all())
@@ -66,7 +68,8 @@ def main():
                                       'Philox sampling on device'.format(B, Tn),
                           'us_per_sample_step': us_step, 'x_realtime_per_utterance': Tn / dt / 16000.0,
                           'launches_per_step': (hp.num_layers + 4) if B < 4 else (2 * hp.num_layers + 5),
-                          'submission': 'plain launches' if not args.graph else 'hipGraph replay (16 steps per graph, captured per call)'},
+                          'streams': args.streams, 'utterances_per_stream': B / float(args.streams),
+                          'submission': 'plain launches' if not (args.graph or args.streams > 1) else 'hipGraph replay (16 steps per graph, captured per call)'},
                'roofline': {'bound': 'hbm', 'achieved': wbytes / (us_step * 1e-6) / 1e9, 'peak': PEAK_HBM_GBPS,
                             'unit': 'GB/s', 'frac': wbytes / (us_step * 1e-6) / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                             'note': 'weight bytes streamed per step / step time; the step is a chain of dependent '

@@ -74,7 +74,7 @@ extern "C" {
 /* `form` of wn_iaf_generate_form / wn_iaf_workspace_bytes_form: which arithmetic ONE call runs in */
 #define WN_FORM_DEFAULT     (-1)  /* what the handle was created for (wn_config.precision / cond_mode) */
 #define WN_FORM_F16X3        0    /* split-fp16 MFMA, conditioning placed by the handle's cond_mode policy */
-#define WN_FORM_F32          1    /* fp32 MFMA: no fp16 range limit, ~2.4x slower */
+#define WN_FORM_F32          1    /* fp32 MFMA (the reference's own arithmetic): no fp16 range limit, ~2.3x slower */
 #define WN_FORM_F16X3_FUSED  2    /* split-fp16 MFMA without the hoisted-conditioning workspace */
 
 #define WN_MAX_DECONV 4
@@ -324,8 +324,9 @@ WN_API int wn_teacher_log_prob(wn_handle* h, const float* out_params, const floa
 
 /* 1 when wn_iaf_generate(B, F) evaluates the per-layer conditioning 1x1s in one hoisted GEMM per
  * deconv stack (the default of the split-fp16 path: the layer kernels then stream 768 B/sample
- * instead of 1536 and the small-dilation layers run two per launch), 0 for cond_mode 1 (fused)
- * and for the fp32 path. */
+ * instead of 1536 and the small-dilation layers run two per launch; since round 6 also the default of the fp32 form:
+ * one fp32 GEMM per deconv stack, the layer kernels on the dilated conv alone), 0 for cond_mode 1 (fused), for fp32
+ * calls whose length is not a multiple of 128 samples and for calls whose projected term would not fit (cond_mode 0). */
 WN_API int wn_iaf_cond_hoisted(const wn_handle* h, int B, int F);
 
 /* 1 when wn_iaf_generate(B, F) runs the residual layers in layer groups (up to five layers per launch with the residual

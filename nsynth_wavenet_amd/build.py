@@ -25,7 +25,7 @@ CODEGEN_FLAGS = ['-O3', '-std=c++17', '-fno-slp-vectorize']
 # The C ABI of include/wnhip.h (WN_API = default visibility) is the library's whole dynamic symbol table: everything
 # else -- the C++ helpers shared by the translation units, STL instantiations -- is local to it.
 VISIBILITY_FLAGS = ['-fvisibility=hidden', '-fvisibility-inlines-hidden']
-SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_x.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
+SOURCES = ['wn_host.cpp', 'wn_deconv.hip', 'wn_iaf.hip', 'wn_iaf_h.hip', 'wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_f.hip', 'wn_iaf_x.hip', 'wn_ar.hip', 'wn_teacher.hip', 'wn_mel.hip']
 HEADERS = ['wn_internal.h', 'wn_codec.h', 'wn_pack_h.h', 'wn_mfma_h.h', 'wn_iaf_c.h', os.path.join(ROOT, 'include', 'wnhip.h')]
 
 

@@ -57,7 +57,7 @@ def iaf_length(hparams, num_frames):
 
 
 # name -> (wn_config.precision, wn_config.cond_mode)
-PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}
+PRECISIONS = {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0), 'f32-fused': (1, 1), 'f32-hoisted': (1, 2)}
 
 
 def default_precision():
@@ -65,7 +65,9 @@ def default_precision():
     product, ~22-bit operands, fp32 accumulate) -- the default; it hoists the per-layer
     conditioning 1x1s into one GEMM per deconv stack and runs the small-dilation layers two per
     launch ('f16x3-hoisted' names that form explicitly; 'f16x3-fused' evaluates the 1x1s inside
-    every layer kernel instead and needs no conditioning workspace); 'f32' = fp32 MFMA."""
+    every layer kernel instead and needs no conditioning workspace); 'f32' = fp32 MFMA, the reference's own
+    arithmetic -- since round 6 with the same split: the conditioning 1x1s in one fp32 GEMM per deconv stack and the residual
+    layers on the dilated conv alone ('f32-hoisted' names that form, 'f32-fused' the one kernel per layer that reads enc itself)."""
     import os
     return os.environ.get('WN_PRECISION', 'f16x3')
 

@@ -868,6 +868,23 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
                     }
                 }
             }
+            // fp32 frame-axis GEMM (wn_iaf_f.hip): output phase p = kernel offset r = (p + pL) % S on input frames f + d - j,
+            // d = (p + pL) / S; one row block per (phase, 64-channel group) inside the fp32 pack above
+            if (!c.use_resize_conv && cin == 256 && lp.taps >= 1 && lp.taps <= 5 && lp.cout % 64 == 0 && (lp.pL + lp.S - 1) / lp.S <= 4) {
+                const int ncg = lp.cout / 64;
+                std::vector<unsigned> tab;
+                for (int p = 0; p < lp.S; ++p)
+                    for (int cg = 0; cg < ncg; ++cg) {
+                        const int r = (p + lp.pL) % lp.S, d = (p + lp.pL) / lp.S;
+                        tab.push_back((unsigned)(lp.w_off + ((size_t)r * nks4 * nmb + (size_t)cg * 4) * 256));
+                        tab.push_back(((unsigned)p << 8) | (unsigned)d);
+                    }
+                blob.resize(align_up(blob.size(), 64));
+                lp.tab_f_off = blob.size();
+                lp.tab_f_R = (int)tab.size() / 2;
+                blob.resize(blob.size() + align_up(tab.size(), 4));
+                memcpy(blob.data() + lp.tab_f_off, tab.data(), tab.size() * sizeof(unsigned));
+            }
             sp.layers.push_back(lp);
             cin = lp.cout;
         }
@@ -878,7 +895,7 @@ int wn_pack_deconv(wn_handle* h, std::vector<float>& blob) {
 int wn_deconv_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_pg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   PG_LDS_BYTES));
-    return WN_OK;
+    return wn_iaf_f_set_attrs(h);       // the fp32 GEMMs with the activation tile in LDS (students and fp32 teachers' upsampler)
 }
 
 // phase-major GEMM output of the largest layer: [B][S][cout][Qp]
@@ -990,6 +1007,21 @@ int wn_run_deconv(wn_handle* h, int si, const float* mel, int B, int F, float* e
                 hipLaunchKernelGGL(kern, g, dim3(256), 0, st, xin, lp.cin, xs, wfr, phase, lp.cout, Qp, lp.S, lp.taps,
                                    lp.inv_scale_h);
             }
+        } else if (lp.tab_f_off && !h->dc_no_pg) {
+            // fp32, 256 input channels: the frame-axis GEMM with the input tile in LDS (wn_iaf_f.hip); its phase-major output
+            // is indexed by (output phase, frame), so the interleave below runs with pL = 0
+            const int Lp = (L + 63) / 64 * 64;
+            wn_deconv_f_gemm(h, x, xs, DC_XOFF, reinterpret_cast<const unsigned*>(h->d_blob + lp.tab_f_off), lp.tab_f_R, lp.taps,
+                             (lp.cout / 16) * 256, phase, lp.S, lp.cout, L, Lp, B, st);
+            dim3 gi(Lp / DC_QT, lp.cout, B);
+            hipLaunchKernelGGL(deconv_interleave_kernel, gi, dim3(256), 0, st, phase, h->d_blob + lp.b_off, y,
+                               lp.cout, Lp, ys, yoff, L, lp.S, 0, c.upsample_act);
+            in_g4 = false;
+            x = y;
+            xs = (int)ys;
+            next = y + (size_t)B * lp.cout * ys;
+            L = Lout;
+            continue;
         } else {
             const int zc = (lp.cout + 255) / 256;
             dim3 g(Qp / DC_QT, lp.S, B * zc);

@@ -158,6 +158,28 @@ __global__ void iaf_start_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// The same into the "Q4" rows of the hoisted fp32 form: l[b][group g = c / 4][column][4 channels] -- one 16-byte word is
+// the MFMA B operand of a lane for a whole K-group, so a layer issues 12 operand loads per block instead of 48 (the vector
+// memory instructions of the planar form cost the K loop 16 % and the launch's first 4 000 cycles: r06 cycle stamps).
+__global__ void iaf_start_q4_kernel(const float* __restrict__ x, const float* __restrict__ wb,
+                                    float* __restrict__ l, int64_t T, int XR, int64_t RS) {
+    const int b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float* xp = x + (size_t)b * XR + IAF_XP + t;
+    const float x0 = xp[-3], x1 = xp[-2], x2 = xp[-1];
+    f4* lp = reinterpret_cast<f4*>(l + (size_t)b * IAF_W * RS) + IAF_LP + t;
+    for (int g = 0; g < IAF_W / 4; ++g) {
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * g + e;
+            o[e] = wb[3 * IAF_W + c] + wb[c] * x0 + wb[IAF_W + c] * x1 + wb[2 * IAF_W + c] * x2;
+        }
+        lp[(size_t)g * RS] = o;
+    }
+}
+
 // ---------------- fused residual layer ----------------
 // Buffer-addressed loads: base pointer + size live in a scalar resource descriptor, the
 // per-lane part of the address is ONE VGPR per tap that stays constant for a tile, and the
@@ -170,6 +192,19 @@ __device__ inline float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 // vector: every r stores element 0 (seen in the ISA as four stores of a0).
 __device__ inline void buf_st(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// 16-byte accesses of the hoisted fp32 form's residual stream ("Q4" rows: four channels of one sample per word).  The store
+// goes through the same guard as every wide residual-stream store of the library (wn_mfma_h.h: buf_st4): gfx950 loses lanes
+// of a buffer_store_dwordx4 whose data a VALU instruction overwrites right behind it.
+__device__ inline f4 buf_ld16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+__device__ inline void buf_st16(f4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u4_t w = __builtin_bit_cast(u4_t, v);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+    asm volatile("s_nop 1" ::"v"(w));
 }
 
 // One-shot staging of a packed weight image into LDS: ALL loads of a thread are issued
@@ -190,44 +225,125 @@ __device__ inline void stage_weights(const float* __restrict__ wpack, float* lds
     __syncthreads();
 }
 
+// two pieces of a pack (NA floats from srcA, NB from srcB) back to back into LDS, all loads before the first store
+template <int NA, int NB, int NT = 256, bool SYNC = true>
+__device__ inline void stage_weights_part(const float* __restrict__ srcA, const float* __restrict__ srcB, float* lds) {
+    constexpr int NF4 = (NA + NB) / 4, NA4 = NA / 4, NCHUNK = (NF4 + NT - 1) / NT;
+    static_assert(NA % 4 == 0 && NB % 4 == 0, "16-byte pieces");
+    f4 tmp[NCHUNK];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+        const int i = k * NT + (int)threadIdx.x;
+        if (i < NF4) tmp[k] = i < NA4 ? reinterpret_cast<const f4*>(srcA)[i] : reinterpret_cast<const f4*>(srcB)[i - NA4];
+    }
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+        const int i = k * NT + (int)threadIdx.x;
+        if (i < NF4) reinterpret_cast<f4*>(lds)[i] = tmp[k];
+    }
+    if (SYNC) __syncthreads();
+}
+
 struct TileSrc {                      // where one wave finds the B operands of one tile
     __amdgpu_buffer_rsrc_t rl, re;    // residual stream rows / upsampled-mel rows of the batch element
     int vo[3];                        // per-lane byte offset for taps t-2d, t-d, t
     int ve;                           // per-lane byte offset into enc
 };
 
-__global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
+// HOIST (round 6): the conditioning 1x1 of every layer and head is evaluated by ONE fp32 GEMM per deconv stack
+// (gemm_f32_kernel, wn_iaf_f.hip) and arrives as the term C in the accumulator layout, bias included -- the kernel then
+// walks the 12 K-groups of the dilated conv only (K = 192 instead of 448: 53 % of a layer's MACs leave the 60 per-layer
+// launches for a GEMM that keeps the matrix pipe busy), its weight image shrinks to 57 KB and it no longer reads enc.
+constexpr int IAF_LAYER_F_FLOATS = 12 * 1024 + IAF_PR_FLOATS + 64 + 64;   // hoisted form: dilated-conv K-groups | PR | bgate | bres
+constexpr int IAF_HEAD_F_FLOATS = 4 * 1024 + 64 * 3 + 4;   // hoisted form: out1 K-groups | bias, wmean, wscale, bmean / bscale
+__device__ inline float softplus_tf(float p);
+
+// LAST (hoisted form): the layer closes a flow and the flow head (parallel_wavenet.py:256-277, :319-324) runs in its epilogue.
+// The head is column-local -- out1 over relu(l), relu, two 64-wide dots, softplus, x <- x s + mean, mean_tot / scale_tot --
+// and the layer's output words ARE its MFMA B operand as they stand in the registers (channel 16 cg + 4 q + jj of lane group q:
+// the K order of the packs): the flow's last l is neither written nor read back and the flow loses a launch (16.8 us each).
+struct HeadF {
+    const float* whead;      // head pack (out1 K-groups at 0, tail at IAF_PH_FLOATS)
+    const float* Ch;         // hoisted term of the head's row block (batch row 0)
+    float* x;
+    float* Mt;
+    float* St;
+    int XR;
+    int64_t T;
+    int first;
+};
+
+// Hoisted form: EIGHT waves per workgroup, two per SIMD, one weight image.  The two waves of a SIMD (w and w + 4) take the
+// workgroup's tiles alternately: with one wave per SIMD the gate (transcendentals), the dependent start of the residual
+// 1x1 and the stores of every tile sat bare between two K loops; now one wave's epilogue runs under the other's MFMAs.
+// One utterance is 1 200 tiles on 256 workgroups = 4.69 per SIMD: five rounds either way (3 + 2 per wave pair).
+#ifndef WN_F32_NH
+#define WN_F32_NH 2
+#endif
+constexpr int iaf_layer_threads(bool hoist) { return hoist ? 256 * WN_F32_NH : 256; }
+#ifdef WN_F32_STAMPS
+// cycle stamps of workgroup 0 of the hoisted layer kernel (a dev build only: scripts/dev_f32_stamps.py): [wave][slot]
+__device__ unsigned long long g_f32_stamps[8 * 32];
+__device__ inline void f32_stamp(int wave_id, int slot) {
+    if (blockIdx.x == WN_F32_STAMPS - 1 && (threadIdx.x & 63) == 0 && slot < 32) g_f32_stamps[wave_id * 32 + slot] = __builtin_amdgcn_s_memtime();
+}
+#define F32_STAMP(slot) f32_stamp((int)(threadIdx.x >> 6), (slot))
+#else
+#define F32_STAMP(slot)
+#endif
+
+template <bool HOIST, bool LAST = false>
+__global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
     const float* __restrict__ lin, float* __restrict__ lout, const float* __restrict__ enc,
-    const float* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles) {
+    const float* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles,
+    const float* __restrict__ C, int64_t c_bstride, const HeadF hd) {
+    static_assert(HOIST || !LAST, "the head runs in the epilogue of the hoisted form only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights<IAF_LAYER_FLOATS>(wpack, lds);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NG = HOIST ? 12 : 28;                 // K-groups of four K-steps
+    constexpr int P_FLOATS = NG * 1024;
+    constexpr int NH = HOIST ? WN_F32_NH : 1;           // wave sets that walk the tiles alternately
+    // wave-uniform values through readfirstlane: a tile index the compiler takes for divergent makes every buffer
+    // descriptor "divergent" and wraps each operand load in a waterfall loop (28 -> 37 us per launch when that happened)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3),
+              half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     const int n = lane & 15, q = lane >> 4;
     const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
-    const f4* PRl = Pl + IAF_P_FLOATS / 4;
-    const float* bg = lds + IAF_P_FLOATS + IAF_PR_FLOATS + q * 16;
+    const f4* PRl = Pl + P_FLOATS / 4;
+    const float* bg = lds + P_FLOATS + IAF_PR_FLOATS + q * 16;
     const float* br = bg + 64;
-    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
-    const int lane_l = (4 * q * (int)RS + wave * 16 + n + IAF_LP) * 4;
+    // fused form: planar rows [64][RS] (4 bytes per column); hoisted form: Q4 rows [16 groups][RS][4] (16 bytes per column)
+    constexpr int CB = HOIST ? 16 : 4;                   // bytes per column of a row
+    const int RS4 = (int)RS * CB, TE4 = (int)TE * 4;
+    const int lane_l = ((HOIST ? q : 4 * q) * (int)RS + wave * 16 + n + IAF_LP) * CB;
     const int lane_e = (4 * q * (int)TE + wave * 16 + n) * 4;
+    const int tile0 = (int)blockIdx.x + half * (int)gridDim.x, tstep = NH * (int)gridDim.x;
 
     auto tile_src = [&](int tile) -> TileSrc {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * 64;
         TileSrc s;
-        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
         s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
-        s.vo[0] = lane_l + (tt - 2 * d) * 4;
-        s.vo[1] = lane_l + (tt - d) * 4;
-        s.vo[2] = lane_l + tt * 4;
+        s.vo[0] = lane_l + (tt - 2 * d) * CB;
+        s.vo[1] = lane_l + (tt - d) * CB;
+        s.vo[2] = lane_l + tt * CB;
         s.ve = lane_e + tt * 4;
         return s;
     };
+    // hoisted term of this wave's column block of a tile: [row block][t / 16][mb][lane][4], one 16-byte load per mb
+    auto load_c = [&](int tile, f4 (&cv)[4], const float* Cb = nullptr) {
+        const int b = tile / tiles_per_row;
+        const int cb = (tile - b * tiles_per_row) * 4 + wave;
+        const f4* cp = reinterpret_cast<const f4*>((Cb ? Cb : C) + (size_t)b * c_bstride) + (size_t)cb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) cv[mb] = __builtin_nontemporal_load(cp + mb * 64);
+    };
     // 28 K-groups of 4 K-steps (16 MFMAs each): groups 0-11 = the three causal taps t-2d,
     // t-d, t of the dilated conv (4 groups of 16 channels each), groups 12-27 = the
-    // conditioning 1x1 over the 256 upsampled-mel channels.
+    // conditioning 1x1 over the 256 upsampled-mel channels (not in the hoisted form).
     auto loadB = [&](const TileSrc& s, int g) -> f4 {
         f4 v;
+        if (HOIST) return buf_ld16(s.rl, s.vo[g >> 2], 4 * (g & 3) * RS4);     // group row 4 cg + q: one word = the K-group's operand
         if (g < 12) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.rl, s.vo[g >> 2], (16 * (g & 3) + jj) * RS4);
@@ -243,27 +359,50 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
     // into the same registers -- every load is issued one whole tile (~15k cycles) before its
     // use, with a single 112-register operand set and no copies.  Weights (A) are read from
     // LDS one K-group ahead into the other half of a register double buffer.
-    f4 bcur[28];
-    if ((int)blockIdx.x < ntiles) {
-        const TileSrc s0 = tile_src(blockIdx.x);
+    f4 bcur[NG], ccur[4], hcur[4];
+    if (HOIST) { F32_STAMP(0); }
+    if (tile0 < ntiles) {
+        const TileSrc s0 = tile_src(tile0);
 #pragma unroll
-        for (int g = 0; g < 28; ++g) bcur[g] = loadB(s0, g);
+        for (int g = 0; g < NG; ++g) bcur[g] = loadB(s0, g);
+        if (HOIST) load_c(tile0, ccur);
+        if (LAST) load_c(tile0, hcur, hd.Ch);
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (HOIST) { F32_STAMP(1); }
+    // the weight image AFTER the first tile's operand loads are in flight (the two latencies overlap)
+    if (HOIST) {
+        // the image of the hoisted form skips the 16 conditioning K-groups of the pack; LAST: the head's image behind it
+        if (LAST) stage_weights_part<4 * 1024, 64 * 3 + 4, 256 * WN_F32_NH, false>(hd.whead, hd.whead + IAF_PH_FLOATS, lds + IAF_LAYER_F_FLOATS);
+        stage_weights_part<12 * 1024, IAF_PR_FLOATS + 128, 256 * WN_F32_NH>(wpack, wpack + IAF_P_FLOATS, lds);
+    } else {
+        stage_weights<IAF_LAYER_FLOATS>(wpack, lds);
+    }
+    if (HOIST) { F32_STAMP(2); }
+    int stamp_i = 0;
+    (void)stamp_i;
+    for (int tile = tile0; tile < ntiles; tile += tstep) {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * 64;
-        const int next = tile + gridDim.x;
+        const int next = tile + tstep;
         const bool has_next = next < ntiles;
         const TileSrc sn = tile_src(has_next ? next : tile);
+        if (HOIST) { F32_STAMP(3 + 4 * stamp_i); }
 
         f4 acc[4], cur[4], a[2][4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bg + mb * 4);
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = HOIST ? ccur[mb] : *reinterpret_cast<const f4*>(bg + mb * 4);
+        if (HOIST && has_next) load_c(next, ccur);
+        f4 hacc[4];
+        if (LAST) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) hacc[mb] = hcur[mb];
+            if (has_next) load_c(next, hcur, hd.Ch);
+        }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) a[0][mb] = Pl[mb * 64];
 #pragma unroll
-        for (int g = 0; g < 28; ++g) {
-            if (g + 1 < 28) {
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) a[(g + 1) & 1][mb] = Pl[((g + 1) * 4 + mb) * 64];
             }
@@ -281,12 +420,14 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
             // LDS weight read of the unrolled loop to the top and spills hundreds of registers
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (HOIST) { F32_STAMP(4 + 4 * stamp_i); }
         // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
         f4 gt[2];
 #pragma unroll
         for (int mg = 0; mg < 2; ++mg)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gt[mg][r] = sigmoidf_(acc[mg][r]) * tanhf_(acc[mg + 2][r]);
+            for (int r = 0; r < 4; ++r)
+                gt[mg][r] = sigmoidf_(acc[mg][r]) * tanhf_(acc[mg + 2][r]);
         // residual 1x1 accumulated onto l: the tap-t operands (groups 8-11) are the C-in
         f4 d2[4];
 #pragma unroll
@@ -301,14 +442,67 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_kernel(
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) d2[mb] = mfma4(ar[mb][jj], gt[j4][jj], d2[mb]);
         }
+        if (HOIST) { F32_STAMP(5 + 4 * stamp_i); }
+        if (LAST) {
+            // flow head on the registers: out1 over relu(l') on top of the head's hoisted tile, then the two projections
+            const f4* PHl = reinterpret_cast<const f4*>(lds + IAF_LAYER_F_FLOATS) + lane;
+            const float* ht = lds + IAF_LAYER_F_FLOATS + 4 * 1024;
+            const float* wm = ht + 64 + q * 16;
+            const float* wsc = wm + 64;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                f4 ah[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) ah[mb] = PHl[(cg * 4 + mb) * 64];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float bv = fmaxf(d2[cg][jj], 0.f);                           // relu(l), :256
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) hacc[mb] = mfma4(ah[mb][jj], bv, hacc[mb]);
+                }
+            }
+            float pm = 0.f, ps = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = fmaxf(hacc[mb][r], 0.f);
+                    pm = fmaf(wm[mb * 4 + r], o, pm);
+                    ps = fmaf(wsc[mb * 4 + r], o, ps);
+                }
+            pm += __shfl_xor(pm, 16);
+            ps += __shfl_xor(ps, 16);
+            pm += __shfl_xor(pm, 32);
+            ps += __shfl_xor(ps, 32);
+            if (q == 0) {
+                const int64_t t = tt + wave * 16 + n;
+                const float mean = pm + ht[192];
+                const float sc = fminf(fmaxf(softplus_tf(ps + ht[193]), EXP_M9), EXP_7);   // :105-114
+                float* xp = hd.x + (size_t)b * hd.XR + IAF_XP + t;
+                *xp = *xp * sc + mean;                                                  // :277
+                float* mp = hd.Mt + (size_t)b * hd.T + t;
+                float* sp = hd.St + (size_t)b * hd.T + t;
+                if (hd.first) { *mp = mean; *sp = sc; }
+                else { *mp = mean + *mp * sc; *sp = *sp * sc; }                         // :322-323
+            }
+            if (HOIST) { F32_STAMP(6 + 4 * stamp_i); }
+            ++stamp_i;
+            continue;
+        }
         const __amdgpu_buffer_rsrc_t ro =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
-        const int vo_out = lane_l + tt * 4;
+            __builtin_amdgcn_make_buffer_rsrc((void*)(lout + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
+        const int vo_out = lane_l + tt * CB;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb) {
+            if (HOIST) {                                   // channels 16 mb + 4 q + (0..3) = one word of group row 4 mb + q
+                buf_st16(d2[mb], ro, vo_out, 4 * mb * RS4);
+                continue;
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                buf_st(d2[mb][r], ro, vo_out, (16 * mb + r) * RS4);
+            for (int r = 0; r < 4; ++r) buf_st(d2[mb][r], ro, vo_out, (16 * mb + r) * RS4);
+        }
+        if (HOIST) { F32_STAMP(6 + 4 * stamp_i); }
+        ++stamp_i;
     }
 }
 
@@ -321,37 +515,51 @@ __device__ inline float softplus_tf(float p) {
     return log1pf(expf(p));
 }
 
+template <bool HOIST>
 __global__ __launch_bounds__(256, 1) void iaf_head_kernel(
     const float* __restrict__ lin, const float* __restrict__ enc, const float* __restrict__ wpack,
     float* __restrict__ x, float* __restrict__ Mt, float* __restrict__ St,
-    int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles) {
+    int64_t RS, int64_t TE, int XR, int64_t T, int first, int tiles_per_row, int ntiles,
+    const float* __restrict__ C, int64_t c_bstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights<IAF_HEAD_FLOATS>(wpack, lds);
+    constexpr int NG = HOIST ? 4 : 20;
+    constexpr int PH_FLOATS = NG * 1024;
+    if (HOIST) stage_weights_part<4 * 1024, 64 * 3 + 4>(wpack, wpack + IAF_PH_FLOATS, lds);
+    else stage_weights<IAF_HEAD_FLOATS>(wpack, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const f4* Pl = reinterpret_cast<const f4*>(lds) + lane;
-    const float* bo = lds + IAF_PH_FLOATS + q * 16;
+    const float* bo = lds + PH_FLOATS + q * 16;
     const float* wm = bo + 64;
     const float* wsc = wm + 64;
-    const float bmean = lds[IAF_PH_FLOATS + 192], bscale = lds[IAF_PH_FLOATS + 193];
-    const int RS4 = (int)RS * 4, TE4 = (int)TE * 4;
-    const int lane_l = (4 * q * (int)RS + wave * 16 + n + IAF_LP) * 4;
+    const float bmean = lds[PH_FLOATS + 192], bscale = lds[PH_FLOATS + 193];
+    constexpr int CB = HOIST ? 16 : 4;                   // bytes per column of an l row (Q4 rows in the hoisted form)
+    const int RS4 = (int)RS * CB, TE4 = (int)TE * 4;
+    const int lane_l = ((HOIST ? q : 4 * q) * (int)RS + wave * 16 + n + IAF_LP) * CB;
     const int lane_e = (4 * q * (int)TE + wave * 16 + n) * 4;
 
-    // 20 K-groups: 0-3 = out1 over relu(l), 4-19 = mel_cond_out1 over the 256 enc channels;
-    // same one-tile-ahead operand prefetch as iaf_layer_kernel.
+    // 20 K-groups: 0-3 = out1 over relu(l), 4-19 = mel_cond_out1 over the 256 enc channels (hoisted form: those arrive
+    // in C, bias included); same one-tile-ahead operand prefetch as iaf_layer_kernel.
     auto tile_src = [&](int tile) -> TileSrc {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * 64;
         TileSrc s;
-        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * RS4, 0x00020000);
+        s.rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lin + (size_t)b * IAF_W * RS), 0, IAF_W * (int)RS * 4, 0x00020000);
         s.re = __builtin_amdgcn_make_buffer_rsrc((void*)(enc + (size_t)b * IAF_CD * TE), 0, 0x7ffffff0, 0x00020000);
-        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * 4;
+        s.vo[0] = s.vo[1] = s.vo[2] = lane_l + tt * CB;
         s.ve = lane_e + tt * 4;
         return s;
     };
+    auto load_c = [&](int tile, f4 (&cv)[4]) {
+        const int b = tile / tiles_per_row;
+        const int cb = (tile - b * tiles_per_row) * 4 + wave;
+        const f4* cp = reinterpret_cast<const f4*>(C + (size_t)b * c_bstride) + (size_t)cb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) cv[mb] = __builtin_nontemporal_load(cp + mb * 64);
+    };
     auto loadB = [&](const TileSrc& s, int g) -> f4 {
         f4 v;
+        if (HOIST) return buf_ld16(s.rl, s.vo[2], 4 * g * RS4);
         if (g < 4) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) v[jj] = buf_ld(s.rl, s.vo[2], (16 * g + jj) * RS4);
@@ -361,11 +569,12 @@ __global__ __launch_bounds__(256, 1) void iaf_head_kernel(
         }
         return v;
     };
-    f4 bcur[20];
+    f4 bcur[NG], ccur[4];
     if ((int)blockIdx.x < ntiles) {
         const TileSrc s0 = tile_src(blockIdx.x);
 #pragma unroll
-        for (int g = 0; g < 20; ++g) bcur[g] = loadB(s0, g);
+        for (int g = 0; g < NG; ++g) bcur[g] = loadB(s0, g);
+        if (HOIST) load_c(blockIdx.x, ccur);
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_row;
@@ -375,12 +584,13 @@ __global__ __launch_bounds__(256, 1) void iaf_head_kernel(
         const TileSrc sn = tile_src(has_next ? next : tile);
         f4 acc[4], a[2][4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb] = *reinterpret_cast<const f4*>(bo + mb * 4);
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = HOIST ? ccur[mb] : *reinterpret_cast<const f4*>(bo + mb * 4);
+        if (HOIST && has_next) load_c(next, ccur);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) a[0][mb] = Pl[mb * 64];
 #pragma unroll
-        for (int g = 0; g < 20; ++g) {
-            if (g + 1 < 20) {
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) a[(g + 1) & 1][mb] = Pl[((g + 1) * 4 + mb) * 64];
             }
@@ -527,6 +737,14 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F, int form) {
 
 }  // namespace
 
+#ifdef WN_F32_STAMPS
+// dev builds only (never in the shipped library): the stamps of the LAST hoisted fp32 layer launch
+extern "C" __attribute__((visibility("default"))) int wn_debug_f32_stamps(unsigned long long* out_host) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 8 * 32) == hipSuccess ? 0 : -5;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
     const wn_config& c = h->cfg;
@@ -628,6 +846,25 @@ int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {
             tb[194] = tb[195] = 0.f;
         }
         h->flows.push_back(fp);
+    }
+    // row-block table of the fp32 conditioning GEMM (wn_iaf_f.hip): the 16 cond K-groups of each pack (layer: K-groups
+    // 12-27, head: 4-19) are contiguous 16 x 1024 floats; the biases (dilated + cond / out1 + cond) sit in lane order
+    // behind the fragments
+    {
+        std::vector<unsigned> tab;
+        for (const IafFlowPack& fp : h->flows) {
+            for (const IafLayerPack& lp : fp.layers) {
+                tab.push_back((unsigned)(lp.off + 12 * 1024));
+                tab.push_back((unsigned)(lp.off + IAF_P_FLOATS + IAF_PR_FLOATS));
+            }
+            tab.push_back((unsigned)(fp.head_off + 4 * 1024));
+            tab.push_back((unsigned)(fp.head_off + IAF_PH_FLOATS));
+        }
+        if (blob.size() >= 0x1ff00000u) return wn_fail(h, WN_EINVAL, "weight blob too large");
+        blob.resize(align_up(blob.size(), 64));
+        h->cond_tab_f_off = blob.size();
+        blob.resize(blob.size() + align_up(tab.size(), 4));
+        memcpy(blob.data() + h->cond_tab_f_off, tab.data(), tab.size() * sizeof(unsigned));
     }
     return WN_OK;
 }
@@ -769,10 +1006,12 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
     const float* x0 = noise ? noise : x0g;
     {
         PrologueArgs A{};
-        // G4 layout (f16x3): 16 interleaved group rows per batch element, each 4*(LP+T) words
-        A.rows = f16x3 ? B * 16 : B * IAF_W;
-        A.rs = f16x3 ? 4 * L.RS : L.RS;
-        A.pad = f16x3 ? 4 * IAF_LP : IAF_LP;
+        // G4 layout (f16x3) and the Q4 rows of the hoisted fp32 form: 16 interleaved group rows per batch element, each
+        // 4*(LP+T) words; fused fp32 form: 64 planar rows
+        const bool rows16 = f16x3 || L.form == WN_COND_HOISTED;
+        A.rows = rows16 ? B * 16 : B * IAF_W;
+        A.rs = rows16 ? 4 * L.RS : L.RS;
+        A.pad = rows16 ? 4 * IAF_LP : IAF_LP;
         A.lA = lA; A.lB = lB; A.x = x; A.x0g = x0g; A.noise = noise; A.status = status;
         A.xrs = (int64_t)L.XR; A.xpad = IAF_XP; A.xrows = 2 * B;
         A.dl_rj = use_groups ? 64 + (int)(L.T / 32) : 0;
@@ -792,10 +1031,14 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         int rc = (pmask & 2) ? wn_run_deconv(h, 0, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec) : WN_OK;
         if (rc) return rc;
         if (hoist) if (int rc2 = part(2)) return rc2;
-        if (hoist && (pmask & 4))
-            wn_iaf_c_cond(enc, h->d_blob, cond_tab, blob_u(use_groups ? h->order_all_off : h->order_id_off),
-                          use_groups ? h->n_nat_all : h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T,
-                          h->num_cu, st);
+        if (hoist && (pmask & 4)) {
+            if (f16x3)
+                wn_iaf_c_cond(enc, h->d_blob, cond_tab, blob_u(use_groups ? h->order_all_off : h->order_id_off),
+                              use_groups ? h->n_nat_all : h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, h->cond_rows, B, L.T,
+                              h->num_cu, st);
+            else
+                wn_iaf_f_cond(h, enc, blob_u(h->cond_tab_f_off), h->cond_rows, Cc, L.c_bstride, L.TE, L.c0, B, L.T, st);
+        }
     }
     const int tiles_per_row = (int)(L.T / 64);
     const int ntiles = B * tiles_per_row;
@@ -808,11 +1051,16 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
             int rc = (pmask & 2) ? wn_run_deconv(h, fp.deconv_stack, mel, B, F, enc, L.TE, scratch, st, f16x3, status, prec) : WN_OK;
             if (rc) return rc;
             if (hoist) if (int rc2 = part(2)) return rc2;
-            if (hoist && (pmask & 4))
-                wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base,
-                              use_groups ? blob_u(h->order_flow_off) + fp.rb_base : blob_u(h->order_id_off),
-                              use_groups ? h->n_nat_flow[k] : (int)fp.layers.size() + 1, Cc, L.c_bstride, L.TE, L.c0,
-                              (int)fp.layers.size() + 1, B, L.T, h->num_cu, st);
+            if (hoist && (pmask & 4)) {
+                if (f16x3)
+                    wn_iaf_c_cond(enc, h->d_blob, cond_tab + fp.rb_base,
+                                  use_groups ? blob_u(h->order_flow_off) + fp.rb_base : blob_u(h->order_id_off),
+                                  use_groups ? h->n_nat_flow[k] : (int)fp.layers.size() + 1, Cc, L.c_bstride, L.TE, L.c0,
+                                  (int)fp.layers.size() + 1, B, L.T, h->num_cu, st);
+                else
+                    wn_iaf_f_cond(h, enc, blob_u(h->cond_tab_f_off) + 2 * fp.rb_base, (int)fp.layers.size() + 1, Cc,
+                                  L.c_bstride, L.TE, L.c0, B, L.T, st);
+            }
         }
         if (int rc = part(3)) return rc;
         if (!(pmask & 8)) continue;
@@ -848,11 +1096,15 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         const bool fuse_start = f16x3 && !hoist && !fp.layers.empty() && fp.layers[0].dilation == 1;
         // hoisted form: layer pairs with small dilations run as one launch (wn_iaf_c_pair); when the flow
         // starts with such a pair the start conv runs inside it as well
-        const bool pair_start = hoist && fp.layers.size() >= 2 && fp.layers[0].dilation == 1 &&
+        const bool pair_start = hoist && f16x3 && fp.layers.size() >= 2 && fp.layers[0].dilation == 1 &&
                                 wn_iaf_c_pair_ok(fp.layers[0].dilation, fp.layers[1].dilation);
         if (fuse_start || pair_start) {
         } else if (f16x3) {
             wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st, status);
+        } else if (hoist) {
+            dim3 g((unsigned)((L.T + 255) / 256), B);
+            hipLaunchKernelGGL(iaf_start_q4_kernel, g, dim3(256), 0, st, x, h->d_blob + fp.start_off, lA, L.T,
+                               L.XR, L.RS);
         } else {
             dim3 g((unsigned)((L.T / 4 + 255) / 256), B);
             hipLaunchKernelGGL(iaf_start_kernel, g, dim3(256), 0, st, x, h->d_blob + fp.start_off, lA, L.T,
@@ -879,7 +1131,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         bool head_done = false;
         for (size_t i = 0; i < fp.layers.size(); ++i) {
             const IafLayerPack& lp = fp.layers[i];
-            if (hoist && i + 1 < fp.layers.size() && wn_iaf_c_pair_ok(lp.dilation, fp.layers[i + 1].dilation)) {
+            if (hoist && f16x3 && i + 1 < fp.layers.size() && wn_iaf_c_pair_ok(lp.dilation, fp.layers[i + 1].dilation)) {
                 const IafLayerPack& lq = fp.layers[i + 1];
                 if (int rc = prof_mark(false, 0)) return rc;
                 wn_iaf_c_pair(lin, lout, Cf + li * rb_floats, Cf + (li + 1) * rb_floats, L.c_bstride,
@@ -890,7 +1142,7 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
                 ++i;
                 continue;
             }
-            if (hoist && i + 1 == fp.layers.size() && wn_iaf_c_last_ok()) {
+            if (hoist && f16x3 && i + 1 == fp.layers.size() && wn_iaf_c_last_ok()) {
                 // last layer of the flow: the head runs in its epilogue
                 if (int rc = prof_mark(false, 0)) return rc;
                 wn_iaf_c_layer_head(lin, Cf + li * rb_floats, Cf + (li + 1) * rb_floats, L.c_bstride,
@@ -901,31 +1153,50 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
                 continue;
             }
             if (int rc = prof_mark(true, 1)) return rc;
-            if (hoist)
+            if (hoist && f16x3)
                 wn_iaf_c_layer(lin, lout, Cf + li * rb_floats, L.c_bstride, h->d_blob + lp.off_h, L.RS, lp.dilation, B,
                                L.T, h->num_cu, st, status);
+            else if (hoist && i + 1 == fp.layers.size()) {
+                // fp32 hoisted form, last layer of the flow: the head runs in its epilogue (iaf_layer_kernel<true, true>)
+                if (int rc = prof_mark(false, 0)) return rc;
+                const HeadF hd{h->d_blob + fp.head_off, Cf + (li + 1) * rb_floats, x, Mt, St, L.XR, L.T, k == 0 ? 1 : 0};
+                hipLaunchKernelGGL((iaf_layer_kernel<true, true>), dim3(grid), dim3(iaf_layer_threads(true)),
+                                   (IAF_LAYER_F_FLOATS + IAF_HEAD_F_FLOATS) * sizeof(float), st, lin, lout, encc,
+                                   h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row, ntiles, Cf + li * rb_floats,
+                                   L.c_bstride, hd);
+                head_done = true;
+                ++li;
+                continue;
+            } else if (hoist)
+                hipLaunchKernelGGL((iaf_layer_kernel<true, false>), dim3(grid), dim3(iaf_layer_threads(true)), IAF_LAYER_F_FLOATS * sizeof(float), st,
+                                   lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row, ntiles,
+                                   Cf + li * rb_floats, L.c_bstride, HeadF{});
             else if (f16x3)
                 wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st, status,
                                (li == 0 && fuse_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off);
             else
-                hipLaunchKernelGGL(iaf_layer_kernel, dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
+                hipLaunchKernelGGL((iaf_layer_kernel<false, false>), dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
                                    lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
-                                   ntiles);
+                                   ntiles, (const float*)nullptr, (int64_t)0, HeadF{});
             float* t = lin; lin = lout; lout = t;
             ++li;
         }
         if (int rc = prof_mark(false, 0)) return rc;
         if (head_done) {
-        } else if (hoist)
+        } else if (hoist && !f16x3)
+            hipLaunchKernelGGL(iaf_head_kernel<true>, dim3(grid), dim3(256), IAF_HEAD_F_FLOATS * sizeof(float), st, lin,
+                               encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
+                               tiles_per_row, ntiles, Cf + li * rb_floats, L.c_bstride);
+        else if (hoist)
             wn_iaf_c_head(lin, Cf + li * rb_floats, L.c_bstride, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.XR, L.T,
                           k == 0 ? 1 : 0, B, h->num_cu, st);
         else if (f16x3)
             wn_iaf_h_head(lin, enc, h->d_blob + fp.head_off_h, x, Mt, St, L.RS, L.TE, L.c0, L.XR, L.T, k == 0 ? 1 : 0, B,
                           h->num_cu, st);
         else
-            hipLaunchKernelGGL(iaf_head_kernel, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
+            hipLaunchKernelGGL(iaf_head_kernel<false>, dim3(grid), dim3(256), IAF_HEAD_FLOATS * sizeof(float), st, lin,
                                encc, h->d_blob + fp.head_off, x, Mt, St, L.RS, L.TE, L.XR, L.T, k == 0 ? 1 : 0,
-                               tiles_per_row, ntiles);
+                               tiles_per_row, ntiles, (const float*)nullptr, (int64_t)0);
     }
     if (int rc = part(0)) return rc;
     {
@@ -974,16 +1245,22 @@ int wn_iaf_set_attrs(wn_handle* h) {
     if (rc) return rc;
     rc = wn_iaf_g_set_attrs(h);
     if (rc) return rc;
-    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel),
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_FLOATS * sizeof(float)));
-    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel),
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * sizeof(float)));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_F_FLOATS * sizeof(float)));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (IAF_LAYER_F_FLOATS + IAF_HEAD_F_FLOATS) * sizeof(float)));
     return WN_OK;
 }
 
 int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form) {
     if (h->generic_student) return WN_COND_FUSED;               // fp32 kernels of wn_iaf_x.hip: no projected term
-    if (wn_form_precision(h, form) != WN_PREC_F16X3 || form == WN_FORM_F16X3_FUSED) return WN_COND_FUSED;
+    if (form == WN_FORM_F16X3_FUSED) return WN_COND_FUSED;
+    // fp32 form (round 6): the same placement policy; its conditioning GEMM walks 128-column tiles
+    if (wn_form_precision(h, form) != WN_PREC_F16X3 && T % 128 != 0) return WN_COND_FUSED;
     int mode = h->cfg.cond_mode;
     if (mode == WN_COND_AUTO) mode = h->cond_env_mode;           // WN_COND, resolved once in wn_create
     if (mode == WN_COND_FUSED) return WN_COND_FUSED;

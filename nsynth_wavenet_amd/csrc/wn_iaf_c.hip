@@ -197,8 +197,10 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 }
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][0], acc[mb][nb]);
+#if !(WN_F16X2 & 1)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][0], bb[cur][1], acc[mb][nb]);
+#endif
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma_h(a[ks & 1][mb][1], bb[cur][0], acc[mb][nb]);
                 // results of a column block leave while the next one is being computed
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(CK_THREADS) void iaf_cond_h_kernel(
                 // to the end of the K-step and the next one starts by waiting a full L2 round trip for them)
                 if (nb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (WN_F16X2 & 1) ? 8 : 12, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -37,6 +37,10 @@ struct DeconvLayerPack {
     size_t w_off_pg = 0;
     int pg_n = 0, pg_nrg = 0;                                         // phase groups, row groups (512 KB of fragments each)
     int pg_p0[8] = {0}, pg_nph[8] = {0}, pg_d[8] = {0}, pg_rg0[8] = {0};   // first phase, phases (4 | 2), input column offset, first row group
+    // fp32 frame-axis GEMM (gemm_f32_kernel<4, true>, wn_iaf_f.hip): uint32 table of tab_f_R = S * cout / 64 pairs
+    // {float offset of the row block's first K-group inside w_off's pack, (phase << 8) | input column shift d}; 0 = not available
+    size_t tab_f_off = 0;
+    int tab_f_R = 0;
 };
 
 struct DeconvStackPack {
@@ -143,6 +147,9 @@ struct wn_handle {
     // every layer and head ("row block"), flow after flow, stored as uint32 inside the blob
     size_t cond_tab_off = 0;
     int cond_rows = 0;
+    // the same table for the fp32 form (wn_iaf_f.hip): {float offset of the row block's 16 cond K-groups, float offset of its
+    // 64 biases in lane order} per row block, flow after flow (layers, then the head)
+    size_t cond_tab_f_off = 0;
     // row-block orders of the conditioning GEMM (uint32 tables inside the blob, each cond_rows long): identity; all
     // flows' natural row blocks first, then the decimated ones (shared deconv stack, wn_iaf_g.hip's plan); the same
     // per flow with flow-local indices (private stacks).  n_nat: natural row blocks of the whole student / per flow
@@ -291,6 +298,13 @@ void wn_iaf_c_pair(const float* lin, float* lout, const float* CA, const float* 
                    const float* x, int XR, const float* wstart, unsigned* status);
 void wn_iaf_c_head(const float* lin, const float* C, int64_t c_bstride, const float* wpack, float* x, float* Mt,
                    float* St, int64_t RS, int XR, int64_t T, int first, int B, int num_cu, hipStream_t st);
+// ---- fp32 GEMMs with the activation tile in LDS (wn_iaf_f.hip) ----
+int wn_iaf_f_set_attrs(wn_handle* h);
+bool wn_iaf_f_cond_ok(int64_t T, int c0);
+void wn_iaf_f_cond(const wn_handle* h, const float* enc, const unsigned* tab, int R, float* C, int64_t c_bstride, int64_t TE,
+                   int c0, int B, int64_t T, hipStream_t st);
+void wn_deconv_f_gemm(const wn_handle* h, const float* x, int xs, int xoff, const unsigned* tab, int R, int taps, int a_kstride,
+                      float* yp, int S, int cout, int L, int Lp, int B, hipStream_t st);
 int wn_iaf_form(const wn_handle* h, int B, int64_t T, int form);   // WN_COND_FUSED / _HOISTED for this call (form: WN_FORM_*)
 bool wn_iaf_use_groups(const wn_handle* h, int B, int64_t T, int cond_form);   // layer-group kernel for this call?
 int wn_form_precision(const wn_handle* h, int form);              // WN_PREC_* a call of this form computes in

@@ -14,9 +14,21 @@ constexpr float EXP_7 = 1096.6331584284585f;
 __device__ inline f4 mfma_h(wn_u4 a, wn_u4 b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wn_h8, a), __builtin_bit_cast(wn_h8, b), c, 0, 0, 0);
 }
+// WN_F16X2 (a MEASUREMENT build, never the shipped library: build.py builds it beside libwnhip.so as libwnhip_f16x2*.so for
+// bench.py's labelled `roofline_f16x2` extra): TWO terms per product, wh.xh + wl.xh -- the activations' lo halves are not
+// multiplied, i.e. the activations enter with their 11-bit hi part only.  Narrower than the reference's fp32; it prices the
+// error budget the contract leaves (1e-3) in microseconds and joules.  Bit 0: the conditioning GEMM, bit 1: the residual
+// stack / heads (every mfma3 site).
+#ifndef WN_F16X2
+#define WN_F16X2 0
+#endif
 __device__ inline f4 mfma3(wn_u4 ah, wn_u4 al, wn_u4 bh, wn_u4 bl, f4 c) {
     c = mfma_h(ah, bh, c);
+#if !(WN_F16X2 & 2)
     c = mfma_h(ah, bl, c);
+#else
+    (void)bl;
+#endif
     return mfma_h(al, bh, c);
 }
 // sigmoid(a) * tanh(b) (parallel_wavenet.py:246-250) from PRE-SCALED arguments as = -a log2(e), bt = 2 b log2(e) -- the

@@ -187,7 +187,7 @@ class Engine(object):
                     _ptr(xr), _ptr(mt), _ptr(st), _ptr(ro), _ptr(ws), ws.numel(), self._stream()))
             run(form)
             self._last_ws = ws
-            if check_range and self.precision != 'f32' and T > 0:
+            if check_range and not self.precision.startswith('f32') and T > 0:
                 rc = self.lib.wn_iaf_range_status(self._h, _ptr(ws), self._stream())
                 if rc == _lib.WN_ERANGE:
                     self.range_fallbacks += 1
@@ -205,7 +205,7 @@ class Engine(object):
     def check_range(self):
         """Raise if any iaf_generate(check_range=False) call since the last check left the fp16 range (the outputs of
         such a call are NaN); synchronises the stream once."""
-        if self._last_ws is None or self.precision == 'f32':
+        if self._last_ws is None or self.precision.startswith('f32'):
             return
         with torch.cuda.device(self.device):
             self._check(self.lib.wn_iaf_range_status_since_reset(self._h, _ptr(self._last_ws), self._stream()))

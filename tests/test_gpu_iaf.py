@@ -40,7 +40,7 @@ def test_unknown_forms_are_refused():
     assert _lib.load().wn_create(ctypes.byref(c), ctypes.byref(h)) == -22
 
 
-@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3-fused', 'f16x3-hoisted', 'f32', 'f32-fused'])
 @pytest.mark.parametrize('tag', ['iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'])
 def test_golden_vectors(tag, precision):
     """HIP path vs the committed oracle vectors (shared deconv + centre crop 76; unit-gain

@@ -401,7 +401,7 @@ def test_run_all_eval_staging_and_sweep(tmp_path, monkeypatch):
 
 def test_precision_names_map_to_config_fields():
     hp = cfg.load_hparams(REFERENCE_STYLE_STUDENT)
-    for name, (prec, cond) in {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0)}.items():
+    for name, (prec, cond) in {'f16x3': (0, 0), 'f16x3-fused': (0, 1), 'f16x3-hoisted': (0, 2), 'f32': (1, 0), 'f32-fused': (1, 1), 'f32-hoisted': (1, 2)}.items():
         c = cfg.to_wn_config(hp, precision=name)
         assert (c.precision, c.cond_mode, c.use_resize_conv) == (prec, cond, 0) and list(c.reserved) == [0] * 5
     with pytest.raises(ValueError):

@@ -154,7 +154,7 @@ def test_the_oracle_made_goldens_agree_with_the_reference_code(R, tag):
 # GPU: the HIP engine through the C ABI against the reference-made vectors
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3', 'f16x3-fused', 'f32', 'f32-fused'])
 @pytest.mark.parametrize('tag', STUDENT_GOLD + STUDENT_EXTRA)
 def test_engine_student_against_the_reference_code(R, tag, precision):
     """wn_iaf_generate on the noise the reference graph drew, against what the reference's code computed from it:

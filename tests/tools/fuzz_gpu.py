@@ -16,7 +16,7 @@ t_end = time.time() + budget / 2
 d = json.load(open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json')))
 hp = cfg.load_hparams(d)
 w = wts.synthetic_weights(hp, seed=int(rs.randint(1 << 20)), init='unit' if rs.rand() < 0.5 else 'tf')
-FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f32')
+FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f32', 'f32-fused')
 engs = {p: Engine(d, precision=p).load_weights(w) for p in ('f16x3',) + FORMS}
 os.environ['WN_DC_NO_PG'] = '1'           # (read once, in wn_create) the upsampler's last layer as phase-major GEMM + interleave
 engs['f16x3-nopg'] = Engine(d, precision='f16x3').load_weights(w)
