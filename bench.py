@@ -215,6 +215,66 @@ def teacher_extras(dev, ar_samples):
     return out
 
 
+def cli_e2e(hp_dict, weights, n_files=256, batch=8, frames=384):
+    """End-to-end figure of the drop-in CLI (eval_parallel_wavenet.py:52-69: a directory of wavs in, gen_<name>.wav out):
+    `n_files` synthetic int16 utterances of 4.8 s on a tmpfs, a checkpoint directory in the reference's layout (single *.json,
+    `checkpoint` state file, EMA-keyed tensors), then cli.run -- serial (load, mel, generate, D2H, write per batch, what the
+    reference's loop does) and with the reader / GPU / writer stages overlapped.  files/s, x real time, and the share of the
+    wall time the GPU was generating (HIP events around the generate calls)."""
+    import shutil
+    import tempfile
+    from argparse import Namespace
+    from scipy.io import wavfile
+    from nsynth_wavenet_amd import cli
+    from nsynth_wavenet_amd.wavenet import parallelgen
+    base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+    root = tempfile.mkdtemp(prefix='wn_cli_e2e_', dir=base)
+    try:
+        src, ck = os.path.join(root, 'wavs'), os.path.join(root, 'ckpt')
+        os.makedirs(src)
+        os.makedirs(ck)
+        n = frames * 200 - 100                                 # 1 + n // 200 = `frames` mel frames
+        rs = np.random.RandomState(5)
+        t = np.arange(n) / 16000.0
+        for i in range(n_files):
+            y = 0.3 * np.sin(2 * np.pi * (110.0 + 3.0 * i) * t) + 0.05 * rs.standard_normal(n)
+            wavfile.write(os.path.join(src, 'utt_%04d.wav' % i), 16000, (np.clip(y, -1, 1) * 32767).astype(np.int16))
+        wts.save_checkpoint(os.path.join(ck, 'model.ckpt-1'), weights, cfg.load_hparams(hp_dict))
+        with open(os.path.join(ck, 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: "model.ckpt-1"\n')
+        with open(os.path.join(ck, 'parallel_wavenet.json'), 'w') as f:
+            json.dump(hp_dict, f)
+        out = {}
+        T = None
+        for mode in ('serial', 'pipelined'):
+            dst = os.path.join(root, 'out_' + mode)
+            args = Namespace(ckpt_dir=ck, source_path=src, save_path=dst, sample_length=-1, batch_size=batch, npy_only=False,
+                             log='ERROR', gpu_id=os.environ.get('HIP_VISIBLE_DEVICES', '0'), serial=(mode == 'serial'))
+            if mode == 'serial':                               # engine creation + checkpoint load outside the timed loops
+                parallelgen.load_parallelgen(*cli.resolve_model(ck))
+                warm = Namespace(**dict(vars(args), source_path=os.path.join(src, 'utt_0000.wav'), save_path=os.path.join(root, 'warm')))
+                cli.run(warm, parallelgen.synthesis)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = cli.run(args, parallelgen.synthesis)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            names = sorted(os.listdir(dst))
+            assert len(names) == n_files and names[0] == 'gen_utt_0000.wav', (mode, len(names))
+            sr, a = wavfile.read(os.path.join(dst, names[-1]))
+            T = int(a.shape[0])
+            assert sr == 16000 and a.dtype == np.float32 and T == (frames * 200 // 512) * 512
+            out[mode] = {'seconds': dt, 'files_per_sec': n_files / dt, 'x_realtime': n_files * T / 16000.0 / dt,
+                         'gpu_busy_frac': (st['gpu_ms'] * 1e-3 / dt) if st else None}
+        out.update({'files': n_files, 'batch_size': batch, 'samples_per_file': T, 'storage': 'tmpfs' if base else 'tmp dir',
+                    'note': 'eval_parallel_wavenet.py end to end on this host: int16 wav in, device mel, generate, float32 wav out; '
+                            'serial = the reference\'s loop (eval_parallel_wavenet.py:52-69), pipelined = reader thread | GPU stage | '
+                            'writer thread (cli.run_pipelined); gpu_busy_frac = HIP-event time of the generate calls over wall time'})
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -781,6 +841,11 @@ def main():
         rec['e2e_note'] = 'host numpy mel -> H2D -> generate -> D2H -> host numpy wav ({} calls); `value` is the ' \
                           'HBM-resident rate'.format(n_e2e)
         assert out.shape == (B, T)
+        # (1b) the drop-in CLI end to end (files in, files out)
+        try:
+            rec['cli_e2e'] = cli_e2e(hp_dict, weights)
+        except Exception as e:               # a figure beside the metric: never fail the bench over the host's file system
+            rec['cli_e2e'] = {'error': repr(e)}
         # (2) the same dominant kernel with the GPU filled: 8 utterances per GPU (BASELINE configs[2]'s per-GPU share)
         if B != 8:
             mel8 = torch.from_numpy(np.random.RandomState(777).uniform(0, 1, [8, F, 80]).astype(np.float32)).to(dev)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='AR: hipGraph replay instead of plain launches')
     ap.add_argument('--streams', type=int, default=1,
                     help='AR: cut the batch into this many utterance groups, each an independent chain on its own stream (one shared handle)')
+    ap.add_argument('--threads', action='store_true',
+                    help='AR with --streams G: G host threads, each a fork of the engine (own queue state, own stream) issuing PLAIN launches, instead of one thread replaying hipGraphs')
     ap.add_argument('--config', default=os.path.join(ROOT, 'config_jsons', 'wavenet_mol.json'))
     args = ap.parse_args()
     with open(args.config) as f:
@@ -49,13 +51,39 @@ def main():
     if args.workload == 'ar':
         Tn = args.samples
         enc = torch.as_tensor((rs.standard_normal([B, Tn, Cd]) * 0.1).astype(np.float32)).to(dev)
-        eng.ar_generate(enc, None, seed=1, use_graph=args.graph, streams=args.streams)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = eng.ar_generate(enc, None, seed=2 + i, use_graph=args.graph, streams=args.streams)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / args.steps
+        if args.threads and args.streams > 1:
+            import threading
+            G = args.streams
+            parts = [enc[B * g // G: B * (g + 1) // G].contiguous() for g in range(G)]
+            forks = [eng.fork() for _ in range(G)]
+            streams = [torch.cuda.Stream(dev) for _ in range(G)]
+            outs = [None] * G
+
+            def work(g, seed):
+                with torch.cuda.stream(streams[g]):
+                    outs[g] = forks[g].ar_generate(parts[g], None, seed=seed + g, use_graph=args.graph)
+
+            def run_all(seed):
+                ths = [threading.Thread(target=work, args=(g, seed)) for g in range(G)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                torch.cuda.synchronize(dev)
+            run_all(1)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                run_all(100 + 10 * i)
+            dt = (time.perf_counter() - t0) / args.steps
+            out = {'wav': torch.cat([o['wav'] for o in outs], 0)}
+        else:
+            eng.ar_generate(enc, None, seed=1, use_graph=args.graph, streams=args.streams)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = eng.ar_generate(enc, None, seed=2 + i, use_graph=args.graph, streams=args.streams)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / args.steps
         assert bool(torch.isfinite(out['wav']).all())
         us_step = dt / Tn * 1e6
         # weights streamed once per step (fp32): gate + composite (batch >= 1), res/skip, head
@@ -69,7 +97,8 @@ def main():
                           'us_per_sample_step': us_step, 'x_realtime_per_utterance': Tn / dt / 16000.0,
                           'launches_per_step': (hp.num_layers + 4) if B < 4 else (2 * hp.num_layers + 5),
                           'streams': args.streams, 'utterances_per_stream': B / float(args.streams),
-                          'submission': 'plain launches' if not (args.graph or args.streams > 1) else 'hipGraph replay (16 steps per graph, captured per call)'},
+                          'host_threads': args.streams if args.threads else 1,
+                          'submission': 'plain launches' if (args.threads and not args.graph) or not (args.graph or args.streams > 1) else 'hipGraph replay (16 steps per graph, captured per call)'},
                'roofline': {'bound': 'hbm', 'achieved': wbytes / (us_step * 1e-6) / 1e9, 'peak': PEAK_HBM_GBPS,
                             'unit': 'GB/s', 'frac': wbytes / (us_step * 1e-6) / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                             'note': 'weight bytes streamed per step / step time; the step is a chain of dependent '

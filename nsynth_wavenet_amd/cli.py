@@ -31,6 +31,8 @@ def build_parser(description):
     p.add_argument('--npy_only', default=False, type=bool, help='If True, use only .npy files.')
     p.add_argument('--log', default='INFO', help='DEBUG, INFO, WARN, ERROR, or FATAL.')
     p.add_argument('--gpu_id', default='0', help='GPU used for generation (ignored under torch.distributed.run).')
+    p.add_argument('--serial', action='store_true',
+                   help='(not in the reference) one batch at a time -- load, generate, write -- instead of the overlapped reader / GPU / writer stages')
     return p
 
 
@@ -65,10 +67,12 @@ def list_sources(source_path, npy_only):
     return []
 
 
-def mel_batch(batch_files, sample_length):
-    """[B,F,80] float32 mel for a batch of .wav (featurised) or .npy (precomputed) files."""
+def mel_batch(batch_files, sample_length, data=None):
+    """[B,F,80] float32 mel for a batch of .wav (featurised) or .npy (precomputed) files; `data`: the batch array when a
+    reader thread has loaded it already."""
     from .wavenet import fastgen
-    data = fastgen.load_batch(batch_files, sample_length=sample_length)
+    if data is None:
+        data = fastgen.load_batch(batch_files, sample_length=sample_length)
     if batch_files[0].lower().endswith('.npy'):
         if data.ndim != 3:
             raise ValueError('.npy inputs must be mel arrays [frames, {}]'.format(mel_extractor.NUM_MEL))
@@ -101,9 +105,80 @@ def run(args, synth_fn):
     files = list_sources(source_path, args.npy_only)
     lo, hi = wdist.shard_range(len(files), rank, world)
     files = files[lo:hi]
+    batches = []
     for start in range(0, len(files), args.batch_size):
-        logging.info('generating batch {:d}'.format(start // args.batch_size))
         batch_files = files[start:start + args.batch_size]
         save_names = [os.path.join(save_path, 'gen_' + os.path.splitext(os.path.basename(f))[0] + '.wav')
                       for f in batch_files]
+        batches.append((batch_files, save_names))
+    gen_async = getattr(synth_fn, 'generate_async', None)
+    import torch
+    if gen_async is not None and torch.cuda.is_available() and not getattr(args, 'serial', False) and len(batches) > 1:
+        return run_pipelined(args, hparams, checkpoint_path, batches, gen_async)
+    for i, (batch_files, save_names) in enumerate(batches):
+        logging.info('generating batch {:d}'.format(i))
         synth_fn(hparams, mel_batch(batch_files, args.sample_length), save_names, checkpoint_path)
+    return None
+
+
+def run_pipelined(args, hparams, checkpoint_path, batches, gen_async, depth=3):
+    """The loop of eval_parallel_wavenet.py:52-69 (load batch -> mel -> sess.run -> write) as three overlapped stages: a reader
+    thread loads and pads the next batches (fastgen.load_batch), this thread featurises on the device and enqueues the
+    generation and the device-to-host copy without synchronising, a writer thread waits for each batch's event and writes its
+    gen_<name>.wav files.  The parallel student needs ~1.2 ms of GPU time per 4.8 s utterance: run serially the drop-in CLI
+    spends nearly all of its wall time in file I/O.  Returns {'files', 'gpu_ms'} (bench.py's `cli_e2e`)."""
+    import queue
+    import threading
+    import torch
+    from .wavenet import fastgen
+    loaded, to_write = queue.Queue(maxsize=depth), queue.Queue(maxsize=depth)
+    errors = []
+
+    def reader():
+        try:
+            for batch_files, save_names in batches:
+                loaded.put((batch_files, save_names, fastgen.load_batch(batch_files, sample_length=args.sample_length)))
+        except BaseException as e:           # noqa: B902 -- handed to the main thread
+            errors.append(e)
+        finally:
+            loaded.put(None)
+
+    stats = {'files': 0, 'gpu_ms': 0.0}
+
+    def writer():
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                host, done, (ev0, ev1), save_names = item
+                done.synchronize()
+                stats['gpu_ms'] += ev0.elapsed_time(ev1)
+                fastgen.save_batch(host.numpy(), save_names)
+                stats['files'] += len(save_names)
+        except BaseException as e:           # noqa: B902
+            errors.append(e)
+
+    tr, tw = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+    tr.start()
+    tw.start()
+    i = 0
+    while True:
+        item = loaded.get()
+        if item is None or errors:
+            break
+        batch_files, save_names, data = item
+        logging.info('generating batch {:d}'.format(i))
+        host, done, evs = gen_async(hparams, mel_batch(batch_files, args.sample_length, data=data), checkpoint_path)
+        while not errors:                     # (a writer that died must not leave this thread blocked on a full queue)
+            try:
+                to_write.put((host, done, evs, save_names), timeout=0.5)
+                break
+            except queue.Full:
+                pass
+        i += 1
+    to_write.put(None)
+    tw.join()
+    if errors:
+        raise errors[0]
+    return stats

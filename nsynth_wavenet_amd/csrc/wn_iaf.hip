@@ -244,6 +244,21 @@ __device__ inline void stage_weights_part(const float* __restrict__ srcA, const 
     if (SYNC) __syncthreads();
 }
 
+// LDS-DMA the compiler does not see (16 B per lane: lane i's bytes land at lds_byte_addr + 16 i), issued from inline asm:
+// through the builtin every later LDS access of the wave would be preceded by s_waitcnt vmcnt(0) (wn_iaf_g.hip has the
+// same helper and the measurement).  Completion is the caller's business: s_waitcnt vmcnt(0) before the barrier.
+__device__ inline void f_dma16(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+// `floats` (a multiple of 4) from src to LDS byte address dst, 1 KB per instruction, spread over the workgroup's waves
+__device__ inline void f_dma_image(const float* src, unsigned dst, int floats, int wave, int lane, int nwaves) {
+    const int full = floats >> 8, rem = (floats & 255) >> 2;
+    for (int i = wave; i < full; i += nwaves) f_dma16(src + (size_t)(i * 64 + lane) * 4, dst + i * 1024);
+    if (rem && wave == full % nwaves && lane < rem) f_dma16(src + (size_t)(full * 64 + lane) * 4, dst + full * 1024);
+}
+
 struct TileSrc {                      // where one wave finds the B operands of one tile
     __amdgpu_buffer_rsrc_t rl, re;    // residual stream rows / upsampled-mel rows of the batch element
     int vo[3];                        // per-lane byte offset for taps t-2d, t-d, t
@@ -281,16 +296,6 @@ struct HeadF {
 #define WN_F32_NH 2
 #endif
 constexpr int iaf_layer_threads(bool hoist) { return hoist ? 256 * WN_F32_NH : 256; }
-#ifdef WN_F32_STAMPS
-// cycle stamps of workgroup 0 of the hoisted layer kernel (a dev build only: scripts/dev_f32_stamps.py): [wave][slot]
-__device__ unsigned long long g_f32_stamps[8 * 32];
-__device__ inline void f32_stamp(int wave_id, int slot) {
-    if (blockIdx.x == WN_F32_STAMPS - 1 && (threadIdx.x & 63) == 0 && slot < 32) g_f32_stamps[wave_id * 32 + slot] = __builtin_amdgcn_s_memtime();
-}
-#define F32_STAMP(slot) f32_stamp((int)(threadIdx.x >> 6), (slot))
-#else
-#define F32_STAMP(slot)
-#endif
 
 template <bool HOIST, bool LAST = false>
 __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
@@ -360,7 +365,19 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
     // use, with a single 112-register operand set and no copies.  Weights (A) are read from
     // LDS one K-group ahead into the other half of a register double buffer.
     f4 bcur[NG], ccur[4], hcur[4];
-    if (HOIST) { F32_STAMP(0); }
+    if (HOIST) {
+        // the weight image by LDS-DMA, requested FIRST (no registers, no wait): the image of the hoisted form skips the 16
+        // conditioning K-groups of the pack; LAST: the head's image behind it.  It lands while the first tile's operands load.
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        constexpr int NWV = 4 * NH;
+        f_dma_image(wpack, lds_base, 12 * 1024, wv, lane, NWV);
+        f_dma_image(wpack + IAF_P_FLOATS, lds_base + 12 * 1024 * 4, IAF_PR_FLOATS + 128, wv, lane, NWV);
+        if (LAST) {
+            f_dma_image(hd.whead, lds_base + IAF_LAYER_F_FLOATS * 4, 4 * 1024, wv, lane, NWV);
+            f_dma_image(hd.whead + IAF_PH_FLOATS, lds_base + (IAF_LAYER_F_FLOATS + 4 * 1024) * 4, 64 * 3 + 4, wv, lane, NWV);
+        }
+    }
     if (tile0 < ntiles) {
         const TileSrc s0 = tile_src(tile0);
 #pragma unroll
@@ -368,25 +385,21 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
         if (HOIST) load_c(tile0, ccur);
         if (LAST) load_c(tile0, hcur, hd.Ch);
     }
-    if (HOIST) { F32_STAMP(1); }
-    // the weight image AFTER the first tile's operand loads are in flight (the two latencies overlap)
     if (HOIST) {
-        // the image of the hoisted form skips the 16 conditioning K-groups of the pack; LAST: the head's image behind it
-        if (LAST) stage_weights_part<4 * 1024, 64 * 3 + 4, 256 * WN_F32_NH, false>(hd.whead, hd.whead + IAF_PH_FLOATS, lds + IAF_LAYER_F_FLOATS);
-        stage_weights_part<12 * 1024, IAF_PR_FLOATS + 128, 256 * WN_F32_NH>(wpack, wpack + IAF_P_FLOATS, lds);
+        // the DMA requests are older than the tile loads and vmcnt retires in order: waiting for everything is the wait
+        // for the tile's operands, which the first K-group needs anyway
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     } else {
+        // the weight image AFTER the first tile's operand loads are in flight (the two latencies overlap)
         stage_weights<IAF_LAYER_FLOATS>(wpack, lds);
     }
-    if (HOIST) { F32_STAMP(2); }
-    int stamp_i = 0;
-    (void)stamp_i;
     for (int tile = tile0; tile < ntiles; tile += tstep) {
         const int b = tile / tiles_per_row;
         const int tt = (tile - b * tiles_per_row) * 64;
         const int next = tile + tstep;
         const bool has_next = next < ntiles;
         const TileSrc sn = tile_src(has_next ? next : tile);
-        if (HOIST) { F32_STAMP(3 + 4 * stamp_i); }
 
         f4 acc[4], cur[4], a[2][4];
 #pragma unroll
@@ -420,7 +433,6 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
             // LDS weight read of the unrolled loop to the top and spills hundreds of registers
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (HOIST) { F32_STAMP(4 + 4 * stamp_i); }
         // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
         f4 gt[2];
 #pragma unroll
@@ -442,7 +454,6 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) d2[mb] = mfma4(ar[mb][jj], gt[j4][jj], d2[mb]);
         }
-        if (HOIST) { F32_STAMP(5 + 4 * stamp_i); }
         if (LAST) {
             // flow head on the registers: out1 over relu(l') on top of the head's hoisted tile, then the two projections
             const f4* PHl = reinterpret_cast<const f4*>(lds + IAF_LAYER_F_FLOATS) + lane;
@@ -485,8 +496,6 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
                 if (hd.first) { *mp = mean; *sp = sc; }
                 else { *mp = mean + *mp * sc; *sp = *sp * sc; }                         // :322-323
             }
-            if (HOIST) { F32_STAMP(6 + 4 * stamp_i); }
-            ++stamp_i;
             continue;
         }
         const __amdgpu_buffer_rsrc_t ro =
@@ -501,8 +510,6 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st(d2[mb][r], ro, vo_out, (16 * mb + r) * RS4);
         }
-        if (HOIST) { F32_STAMP(6 + 4 * stamp_i); }
-        ++stamp_i;
     }
 }
 
@@ -736,14 +743,6 @@ IafLayout iaf_layout(const wn_handle* h, int B, int F, int form) {
 }
 
 }  // namespace
-
-#ifdef WN_F32_STAMPS
-// dev builds only (never in the shipped library): the stamps of the LAST hoisted fp32 layer launch
-extern "C" __attribute__((visibility("default"))) int wn_debug_f32_stamps(unsigned long long* out_host) {
-    (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 8 * 32) == hipSuccess ? 0 : -5;
-}
-#endif
 
 // ---------------------------------------------------------------------------
 int wn_pack_iaf(wn_handle* h, std::vector<float>& blob) {

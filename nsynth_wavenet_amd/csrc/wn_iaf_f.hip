@@ -133,16 +133,23 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(const GfArgs A) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f4){0.f, 0.f, 0.f, 0.f};
-            f4 a[2][4];
+            // fragments NBUF - 1 K-groups ahead of their use: one K-group of the narrow (64-column) deconv task is 2 000
+            // cycles of MFMA per wave, less than an L2 round trip under this kernel's own 5 TB/s of fragment traffic
+            constexpr int NBUF = DECONV ? 4 : 2;
+            f4 a[NBUF][4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[0][mb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, 0, 0));
+            for (int p = 0; p < NBUF - 1; ++p)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    a[p][mb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, p * ks4, 0));
             // one K-group: 16 input channels x the tile's NB column blocks = 16 NB MFMAs
             auto kgroup = [&](int kg, auto cur_c) {
                 constexpr int cur = decltype(cur_c)::value;
-                if (kg + 1 < A.nkg) {
+                if (kg + NBUF - 1 < A.nkg) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
-                        a[cur ^ 1][mb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, (kg + 1) * ks4, 0));
+                        a[(cur + NBUF - 1) % NBUF][mb] =
+                            __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, (kg + NBUF - 1) * ks4, 0));
                 }
                 const int cg = kg & 15;                           // channel group of 16
                 const int colb = DECONV ? GF_HALO + dshift - (kg >> 4) : 0;   // tap j = kg / 16 reads x[f + d - j]
@@ -165,9 +172,13 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(const GfArgs A) {
                         for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma4(a[cur][mb][jj], bw[nb & 1][jj], acc[mb][nb]);
                 }
             };
-            for (int kg = 0; kg < A.nkg; kg += 2) {
+            for (int kg = 0; kg < A.nkg; kg += NBUF) {            // (nkg is a multiple of 16)
                 kgroup(kg, std::integral_constant<int, 0>{});
                 kgroup(kg + 1, std::integral_constant<int, 1>{});
+                if (NBUF == 4) {
+                    kgroup(kg + 2, std::integral_constant<int, 2 % NBUF>{});
+                    kgroup(kg + 3, std::integral_constant<int, 3 % NBUF>{});
+                }
             }
             if (!DECONV) {
                 // bias of the row block (the layer's dilated-conv + cond biases / the head's out1 + cond biases, in lane order)

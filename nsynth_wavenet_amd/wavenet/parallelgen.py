@@ -61,3 +61,30 @@ def synthesis(hparams, mel, save_paths, checkpoint_path):
     assert len(save_paths) == batch_size
     audio = generate(hparams, mel, checkpoint_path)
     fastgen.save_batch(audio, save_paths)
+
+
+def generate_async(hparams, mel, checkpoint_path, seed=None):
+    """The GPU stage of a pipelined driver (cli.run): enqueue mel -> audio and the device-to-host copy of the result into a
+    pinned buffer, return (pinned float32 tensor [B,T], event recorded behind the copy, enqueue time stamp) WITHOUT
+    synchronising -- the caller's writer thread waits on the event while the next batch is already running."""
+    eng = load_parallelgen(hparams, checkpoint_path)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    if torch.is_tensor(mel):
+        mel_d = mel.to(device=eng.device, dtype=torch.float32).contiguous()
+    else:
+        mel_d = torch.as_tensor(np.ascontiguousarray(mel), dtype=torch.float32).to(eng.device, non_blocking=True)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    out = eng.iaf_generate(mel_d, seed=seed, want=('wav',), check_range=True)['wav']
+    ev1.record()
+    host = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(out, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return host, done, (ev0, ev1)
+
+
+# cli.run pipelines this driver: reader thread (files -> numpy) | GPU stage (generate_async) | writer thread (wav files)
+synthesis.generate_async = generate_async
