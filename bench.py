@@ -167,8 +167,8 @@ def teacher_extras(dev, ar_samples):
     wbytes = 4.0 * (hp.num_layers * (G * (3 * W + Cd) + (W + S) * (G // 2)) + (hp.num_layers - 1) * G * (G // 2) +
                     S * W + S * (S + Cd) + OW * S)
     mac_step = wbytes / 4.0
-    for B, key in ((1, 'ar_b1'), (64, 'ar_b64')):
-        Tn = ar_samples
+    for B, key in ((1, 'ar_b1'), (64, 'ar_b64'), (256, 'ar_b256')):
+        Tn = ar_samples if B <= 64 else max(160, ar_samples // 4)
         enc = torch.as_tensor((rs.standard_normal([B, Tn, Cd]) * 0.1).astype(np.float32)).to(dev)
         eng.ar_generate(enc[:, :64], None, seed=1, use_graph=False)
         torch.cuda.synchronize(dev)
@@ -188,6 +188,41 @@ def teacher_extras(dev, ar_samples):
                      '(launch-latency bound, DESIGN.md 3.4)'}
         r.update(three_fracs(2.0 * mac_step * B, wbytes, us_step * 1e-6, 1, PEAK_F32_MFMA_TFLOPS))
         out[key] = r
+    # Round 6: independent utterance groups as chains on their own streams against ONE handle (Engine.fork per host thread,
+    # plain launches).  The single-stream timeline has a kernel resident 94 % of the time (profiles/r06_ar_streams_timeline.txt):
+    # the step's kernels are latency-bound themselves, the GPU does not idle between them -- two chains overlap for half of
+    # the span and buy ~1.2x; the batch is the lever (ar_b256 above: 3x ar_b64; 1 024 utterances: 5x, profiles/r06_ar_batch_and_streams.txt).
+    try:
+        import threading
+        B, G, Tn = 64, 2, ar_samples
+        enc = torch.as_tensor((rs.standard_normal([B, Tn, Cd]) * 0.1).astype(np.float32)).to(dev)
+        parts = [enc[B * g // G: B * (g + 1) // G].contiguous() for g in range(G)]
+        forks = [eng.fork() for _ in range(G)]
+        streams = [torch.cuda.Stream(dev) for _ in range(G)]
+
+        def work(g, n, seed):
+            with torch.cuda.stream(streams[g]):
+                forks[g].ar_generate(parts[g][:, :n], None, seed=seed + g, use_graph=False)
+
+        def run_all(n, seed):
+            ths = [threading.Thread(target=work, args=(g, n, seed)) for g in range(G)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize(dev)
+        run_all(64, 1)
+        t0 = time.perf_counter()
+        run_all(Tn, 7)
+        dt = time.perf_counter() - t0
+        out['ar_b64_s2'] = {'workload': 'as ar_b64, the 64 utterances as {} independent groups: {} host threads, one stream and one queue state each, ONE shared handle, plain launches'.format(G, G),
+                            'samples_per_sec': B * Tn / dt, 'us_per_sample_step': dt / Tn * 1e6, 'x_realtime_aggregate': B * Tn / dt / 16000.0,
+                            'vs_ar_b64': (B * Tn / dt) / out['ar_b64']['samples_per_sec'],
+                            'note': 'profiles/r06_ar_streams_timeline.txt: kernels of the two chains overlap for 0.53 of the span, each as long as alone'}
+        for f_ in forks:
+            f_.close()
+    except Exception as e:                   # a labelled extra: never fail the bench over it
+        out['ar_b64_s2'] = {'error': repr(e)}
     F = 384
     T = F * cfg.frame_shift(hp)
     mel = torch.as_tensor(rs.uniform(0, 1, [1, F, 80]).astype(np.float32)).to(dev)
@@ -273,6 +308,90 @@ def cli_e2e(hp_dict, weights, n_files=256, batch=8, frames=384):
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+F16X2_LIBS = (('three terms (the shipped arithmetic)', 'libwnhip.so'),
+              ('two terms in the conditioning GEMM', 'libwnhip_f16x2c.so'),
+              ('two terms in the conditioning GEMM, the residual stack and the heads', 'libwnhip_f16x2.so'))
+
+
+def f16x2_probe():
+    """Child process of the `roofline_f16x2` extra (WN_LIB_PATH names the library): distance from the REFERENCE CODE's vectors
+    (tests/golden/ref_float_full.npz: configs[1] at full size; ref_float.npz: the small student cases incl. the unit-gain one on
+    a +-28 range) and sustained time / power / energy per call, as one JSON line."""
+    from nsynth_wavenet_amd.engine import Engine
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    RF = np.load(os.path.join(gold, 'ref_float_full.npz'))
+    cfgd = json.loads(str(RF['full/in_cfg_json']))
+    hp = cfg.load_hparams(cfgd)
+    w = wts.synthetic_weights(hp, seed=int(RF['full/in_seed']), init=str(RF['full/in_init']))
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    eng = Engine(cfgd, device=dev).load_weights(w)
+    u = np.random.RandomState(12346).uniform(1e-5, 1 - 1e-5, [1, 76800]).astype(np.float32).astype(np.float64)
+    noise = (np.log(u) - np.log(1.0 - u)).astype(np.float32)
+    mel = torch.from_numpy(RF['full/in_mel']).to(dev)
+    out = eng.iaf_generate(mel, noise, want=('x', 'idx'))
+    x_ref = RF['full/x_f64']
+    res = {'full_size_max_abs_err': float(np.abs(out['x'].cpu().numpy() - x_ref).max()), 'full_size_range': float(np.abs(x_ref).max()),
+           'full_size_index_flips': int((out['idx'].cpu().numpy().astype(np.int64) != RF['full/idx_i16'].astype(np.int64)).sum())}
+    R = np.load(os.path.join(gold, 'ref_float.npz'))
+    small = {}
+    for tag in ('iaf_logistic_tf', 'iaf_logistic_unit', 'iaf_gauss_perflow', 'iaf_mulaw'):
+        g = np.load(os.path.join(gold, tag + '.npz'))
+        c2 = json.loads(str(g['cfg_json']))
+        e2 = Engine(c2, device=dev).load_weights(wts.synthetic_weights(cfg.load_hparams(c2), seed=int(g['seed']), init=str(g['init'])))
+        x = e2.iaf_generate(g['mel'], R[tag + '/rand_input_f64'].astype(np.float32), want=('x',), check_range=False)['x'].cpu().numpy()
+        ref = R[tag + '/x_f64']
+        small[tag] = {'max_abs_err': float(np.abs(x - ref).max()), 'range': float(np.abs(ref).max())}
+        e2.close()
+    res['small_cases'] = small
+    for i in range(40):
+        eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
+    torch.cuda.synchronize()
+    pw = measure_power(eng, mel, 0, 0, seconds=1.5)
+    if pw:
+        res.update({'ms_per_call_sustained': pw['ms_per_step_sustained'], 'avg_W': pw['avg_W'], 'avg_sclk_MHz': pw['avg_sclk_MHz'],
+                    'J_per_call': pw['J_per_step']})
+    else:
+        t0 = time.perf_counter()
+        for i in range(200):
+            eng.iaf_generate(mel, None, seed=i, want=('wav',), check_range=False)
+        torch.cuda.synchronize()
+        res['ms_per_call_sustained'] = (time.perf_counter() - t0) / 200 * 1e3
+    eng.close()
+    print(json.dumps(res), flush=True)
+
+
+def roofline_f16x2():
+    """`roofline_f16x2`: what the unspent error budget would buy -- NARROWER THAN THE REFERENCE, NOT THE METRIC.  The
+    contract allows 1e-3 max-abs; the shipped split-fp16 arithmetic (three fp16 MFMAs per product, 22-bit operands) is at
+    3e-7.  Two measurement builds drop the term with the activations' lo halves (wh.xh + wl.xh; build.py: build_f16x2); each
+    is run in a child process through WN_LIB_PATH and held to the vectors the reference's own code produced."""
+    out = {'label': 'narrower than the reference: not the metric', 'variants': []}
+    lib_dir = os.path.join(ROOT, 'nsynth_wavenet_amd', 'lib')
+    for what, name in F16X2_LIBS:
+        path = os.path.join(lib_dir, name)
+        if not os.path.exists(path):
+            out['variants'].append({'arithmetic': what, 'library': name, 'error': 'not built (python -m nsynth_wavenet_amd.build --f16x2)'})
+            continue
+        env = dict(os.environ, WN_LIB_PATH=path)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--f16x2-probe'], env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=300)
+            line = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+            d = json.loads(line[-1]) if line else {'error': r.stderr.decode(errors='replace')[-400:]}
+        except Exception as e:               # a labelled extra: never fail the bench over it
+            d = {'error': repr(e)}
+        d.update({'arithmetic': what, 'library': name})
+        out['variants'].append(d)
+    base = out['variants'][0]
+    for v in out['variants'][1:]:
+        if 'ms_per_call_sustained' in v and 'ms_per_call_sustained' in base:
+            v['time_vs_shipped'] = v['ms_per_call_sustained'] / base['ms_per_call_sustained']
+            if 'J_per_call' in v and 'J_per_call' in base:
+                v['energy_vs_shipped'] = v['J_per_call'] / base['J_per_call']
+    return out
 
 
 def free_port():
@@ -713,9 +832,12 @@ def main():
                     help='untimed steps before the --warmup steps: -1 (default) = until two consecutive 10-call means agree within '
                          '0.5 %% (at most 0.3 s: the GPU leaves its idle clocks); N >= 0 = exactly N (0 = the bare protocol)')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--f16x2-probe', action='store_true', help=argparse.SUPPRESS)   # child process of the roofline_f16x2 extra
     ap.add_argument('--same-gpu', action='store_true', help=argparse.SUPPRESS)   # N ranks on GPU 0 over gloo: code-path check on a one-GPU box
     args = ap.parse_args()
 
+    if args.f16x2_probe:
+        return f16x2_probe()
     rank, world, local = wdist.env_rank_world()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -841,6 +963,8 @@ def main():
         rec['e2e_note'] = 'host numpy mel -> H2D -> generate -> D2H -> host numpy wav ({} calls); `value` is the ' \
                           'HBM-resident rate'.format(n_e2e)
         assert out.shape == (B, T)
+        # (1a) the unspent error budget, priced (a labelled extra: narrower than the reference, never the metric)
+        rec['roofline_f16x2'] = roofline_f16x2()
         # (1b) the drop-in CLI end to end (files in, files out)
         try:
             rec['cli_e2e'] = cli_e2e(hp_dict, weights)

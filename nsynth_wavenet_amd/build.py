@@ -127,5 +127,55 @@ def build(force=False, verbose=True):
     return LIB_PATH
 
 
+# MEASUREMENT builds for bench.py's labelled `roofline_f16x2` extra (never loaded by the product: _lib.py loads libwnhip.so):
+# the split-fp16 contraction with TWO terms per product (wh.xh + wl.xh: the activations' lo halves are not multiplied) in the
+# conditioning GEMM only (-DWN_F16X2=1) and in the conditioning GEMM + residual stack + heads (-DWN_F16X2=3).  Narrower than
+# the reference's fp32 -- it prices the error budget the contract leaves.  Only the sources that hold an mfma3 site of the
+# student path are recompiled; the other objects are the shipped library's.
+F16X2_VARIANTS = {'libwnhip_f16x2c.so': ('1', ['wn_iaf_c.hip']),
+                  'libwnhip_f16x2.so': ('3', ['wn_iaf_c.hip', 'wn_iaf_g.hip', 'wn_iaf_h.hip'])}
+
+
+def build_f16x2(force=False, verbose=True):
+    """Build the two f16x2 measurement libraries next to libwnhip.so (which must exist).  Returns their paths."""
+    out = []
+    hipcc = find_hipcc()
+    have = source_hash()
+    for name, (bits, srcs) in F16X2_VARIANTS.items():
+        path = os.path.join(LIB_DIR, name)
+        stamp = os.path.splitext(path)[0] + '.sha256'
+        if not force and os.path.exists(path) and os.path.exists(stamp) and open(stamp).read().strip() == have + ':' + bits:
+            out.append(path)
+            continue
+        common = ['--offload-arch=gfx950'] + CODEGEN_FLAGS + VISIBILITY_FLAGS + ['-fPIC', '-Wall', '-Wno-unused-function',
+                  '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-DWN_F16X2=' + bits]
+        objs, procs = [], []
+        for s in SOURCES:
+            base = os.path.splitext(s)[0]
+            if s in srcs:
+                obj = os.path.join(LIB_DIR, base + '_x2_' + bits + '.o')
+                cmd = [hipcc] + common + ['-c', os.path.join(CSRC, s), '-o', obj]
+                procs.append((s, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            else:
+                obj = os.path.join(LIB_DIR, base + '.o')
+            objs.append(obj)
+        for s, obj, p_ in procs:
+            o, _ = p_.communicate()
+            if p_.returncode != 0:
+                raise RuntimeError('hipcc failed on {} (f16x2 build):\n{}'.format(s, o.decode(errors='replace')))
+        audit_objects([o for _, o, _ in procs], verbose)
+        vers = os.path.join(LIB_DIR, 'libwnhip.map')
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + VISIBILITY_FLAGS +
+                              ['-Wl,--version-script=' + vers] + objs + ['-o', path])
+        with open(stamp, 'w') as f:
+            f.write(have + ':' + bits + '\n')
+        if verbose:
+            print('built', path, flush=True)
+        out.append(path)
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    if '--f16x2' in sys.argv:
+        print(build_f16x2(force='--force' in sys.argv))

@@ -278,3 +278,42 @@ def test_student_loads_through_a_tf_bundle_and_the_cli(tmp_path, monkeypatch):
     assert np.abs(audio - wav_ref[0]).max() <= 1e-3 and np.mean(audio != wav_ref[0].astype(np.float32)) < 0.02
     eng.close()
     torch.cuda.synchronize()
+
+
+def test_pipelined_cli_writes_what_the_serial_loop_writes(tmp_path):
+    """eval_parallel_wavenet.py over a directory of wavs (ragged lengths, batches of 3, a short last batch): the overlapped
+    reader | GPU | writer stages (cli.run_pipelined, the default) write, file for file and bit for bit, what the reference's
+    one-batch-at-a-time loop (eval_parallel_wavenet.py:52-69; --serial) writes, with the reference's unseeded draws pinned."""
+    import json
+    import torch
+    from scipy.io import wavfile
+    import eval_parallel_wavenet as cli_main
+    from nsynth_wavenet_amd import cli, config as cfg, weights as wts
+    cfgd = dict(load_json('parallel_wavenet.json'), num_iaf_layers=[10, 10])
+    hp = cfg.load_hparams(cfgd)
+    ck = tmp_path / 'ckpt'
+    ck.mkdir()
+    wts.save_checkpoint(str(ck / 'model.ckpt-7'), wts.synthetic_weights(hp, seed=5, init='tf'), hp)
+    (ck / 'parallel_wavenet.json').write_text(json.dumps(cfgd))
+    src = tmp_path / 'wavs'
+    src.mkdir()
+    rs = np.random.RandomState(9)
+    lens = [4700, 5200, 3900, 6100, 5000, 4400, 5600]
+    for i, n in enumerate(lens):
+        y = 0.3 * np.sin(2 * np.pi * (200.0 + 40 * i) * np.arange(n) / 16000.0) + 0.02 * rs.standard_normal(n)
+        wavfile.write(str(src / ('u%02d.wav' % i)), 16000, (np.clip(y, -1, 1) * 32767).astype(np.int16))
+    outs = {}
+    for mode in ('serial', 'pipelined'):
+        dst = tmp_path / ('out_' + mode)
+        argv = ['--ckpt_dir', str(ck), '--source_path', str(src), '--save_path', str(dst), '--batch_size', '3']
+        np.random.seed(4242)
+        cli_main.generate(cli.build_parser('t').parse_args(argv + (['--serial'] if mode == 'serial' else [])))
+        torch.cuda.synchronize()
+        outs[mode] = {f: wavfile.read(str(dst / f))[1] for f in sorted(os.listdir(dst))}
+    assert sorted(outs['serial']) == ['gen_u%02d.wav' % i for i in range(len(lens))] == sorted(outs['pipelined'])
+    for f, a in outs['serial'].items():
+        b = outs['pipelined'][f]
+        assert a.dtype == np.float32 and a.shape == b.shape and a.size > 0 and np.array_equal(a, b), f
+    # a batch is padded to its longest utterance (fastgen.load_batch): files of one batch share a length, a multiple of 512
+    assert len({outs['serial']['gen_u%02d.wav' % i].shape for i in (0, 1, 2)}) == 1
+    assert all(a.shape[0] % 512 == 0 for a in outs['serial'].values())
