@@ -79,7 +79,7 @@ def pmc_replay(B, F, precision='f16x3', hoisted=False, kernel=None):
     on; a summary without a hash, or with another one, is stale and gives None."""
     none = {'traffic': None, 'mfma_util': None, 'kernel_us_per_call': None, 'file': None}
     if precision in ('f32', 'f32-hoisted') and hoisted:
-        names, kernel = [PROFILE_ROUND + '_pmc_summary_f32.json'], kernel or 'iaf_layer_kernel<true>'
+        names, kernel = [PROFILE_ROUND + '_pmc_summary_f32.json'], kernel or 'iaf_layer_kernel<hoist>'
     elif precision.startswith('f32'):
         names, kernel = ['r01_pmc_summary.json'], 'iaf_layer_kernel'
     elif precision in ('f16x3', 'f16x3-hoisted') and hoisted:
@@ -540,12 +540,13 @@ def part_rooflines(eng, hp, B, F, T, part_us, pm):
         sec = part_us['cond_gemm'] * 1e-6
         flop = 2.0 * rows * Cd * B * T
         moved = 4.0 * rows * B * T + stacks * 4.0 * Cd * B * T + 4.0 * rows * Cd        # C written, enc read once per stack, weights
-        tr, mu = pmc_of(['iaf_cond_h_kernel'])
-        r = {'kernel': 'iaf_cond_h_kernel (wn_iaf_c.hip): C[{} x T] = Wcond[{} x {}] . enc, all layers and heads of a deconv stack in '
+        cond_k = 'gemm_f32_kernel<cond>' if f32 else 'iaf_cond_h_kernel'
+        tr, mu = pmc_of([cond_k])
+        r = {'kernel': ('gemm_f32_kernel<8, false> (wn_iaf_f.hip)' if f32 else 'iaf_cond_h_kernel (wn_iaf_c.hip)') + ': C[{} x T] = Wcond[{} x {}] . enc, all layers and heads of a deconv stack in '
                        'one GEMM, written in the accumulator layout of the layer kernels'.format(rows, rows, Cd),
              'bound': 'mfma', 'achieved': flop / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': flop / sec / 1e12 / peak,
              'us_per_call': part_us['cond_gemm'], 'launches_per_call': stacks, 'flop_per_call': flop,
-             'algorithmic_bytes_per_call': moved, 'traffic': tr, 'mfma_util': mu and mu.get('iaf_cond_h_kernel'),
+             'algorithmic_bytes_per_call': moved, 'traffic': tr, 'mfma_util': mu and mu.get(cond_k),
              'pmc_file': pm.get('file'),
              'note': 'co-bound: its output alone (4 B x {} rows per sample) is {:.2f} GB per call, {:.0f} us at the ~5 TB/s '
                      'this part sustains for writes'.format(rows, 4.0 * rows * B * T / 1e9, 4.0 * rows * B * T / 5e12 * 1e6)}
@@ -565,7 +566,8 @@ def part_rooflines(eng, hp, B, F, T, part_us, pm):
             L, cin = Lout, Cd
         flop *= stacks
         moved *= stacks
-        names = ['deconv_mfma_h_kernel<false>', 'deconv_pg_kernel', 'deconv_mfma_hs_kernel<4>', 'deconv_interleave_g4_kernel', 'mel_to_split_kernel']
+        names = ['gemm_f32_kernel<deconv>', 'deconv_mfma_kernel', 'deconv_interleave_kernel', 'mel_to_cm_kernel'] if f32 else \
+            ['deconv_mfma_h_kernel<false>', 'deconv_pg_kernel', 'deconv_mfma_hs_kernel<4>', 'deconv_interleave_g4_kernel', 'mel_to_split_kernel']
         tr, mu = pmc_of(names)
         r = {'kernel': 'upsampler (wn_deconv.hip): {} transposed-conv layers as per-phase split-fp16 GEMMs (deconv_mfma_h[s]_kernel) + '
                        'phase interleave / fp16 split (deconv_interleave_g4_kernel)'.format(nl),
@@ -689,7 +691,7 @@ def roofline_of(eng, B, F, T, layer_ms, layer_launches, clock_hz=None):
     if f32 and hoisted:
         # fp32 form, round 6: the conditioning 1x1s in one fp32 GEMM per deconv stack (gemm_f32_kernel, `roofline_cond`),
         # the per-layer launch keeps the dilated conv, the gate and the residual 1x1 -- K = 192 + 32 instead of 448 + 32
-        kernel_key = 'iaf_layer_kernel<true>'
+        kernel_key = 'iaf_layer_kernel<hoist>'
         flops_per_launch = (LAYER_FLOP_PER_SAMPLE - 2 * 16384) * B * T
         bytes_per_launch = LAYER_BYTES_PER_SAMPLE_HOISTED * B * T
         achieved_tf = flops_per_launch / avg_layer_s / 1e12
@@ -990,7 +992,18 @@ def main():
             r32 = roofline_of(eng32, B, F, T, lms32, ll32, clock_hz_of(clocks_after))
             path_tf = PATH_FLOP_PER_SAMPLE * B * T * n32 / el32 / 1e12
             r32.update({'precision': 'f32', 'steps': n32, 'ms_per_step': el32 / n32 * 1e3, 'samples_per_sec': B * T * n32 / el32,
-                        'path_achieved_tflops': path_tf, 'path_frac_of_f32_mfma_peak': path_tf / PEAK_F32_MFMA_TFLOPS})
+                        'path_achieved_tflops': path_tf, 'path_frac_of_f32_mfma_peak': path_tf / PEAK_F32_MFMA_TFLOPS,
+                        'form': 'hoisted: conditioning in one fp32 GEMM per deconv stack (gemm_f32_kernel), the upsampler\'s last layer as a '
+                                'frame-axis fp32 GEMM, per-layer launches on Q4 rows, the flow head in the last layer\'s epilogue (round 6)'
+                                if eng32.iaf_cond_hoisted(B, F) else 'fused: one kernel per layer reads enc itself'})
+            pu32, n_p32 = measure_parts(eng32, mel, rank, calls=10)
+            r32['kernel_us_per_call'] = dict(pu32, calls=n_p32, sum_us=sum(pu32.values()))
+            pm32 = pmc_replay(B, F, eng32.precision, eng32.iaf_cond_hoisted(B, F), 'iaf_layer_kernel<hoist>')
+            for k_, v_ in part_rooflines(eng32, hp, B, F, T, pu32, pm32).items():
+                r32[k_] = v_
+            pw32 = measure_power(eng32, mel, rank, local, seconds=1.0)
+            if pw32:
+                r32['power'] = {k_: pw32[k_] for k_ in ('avg_W', 'max_W', 'cap_W', 'avg_sclk_MHz', 'ms_per_step_sustained', 'J_per_step')}
             rec['roofline_f32'] = r32
             eng32.close()
     if world > 1 and not args.no_extras:

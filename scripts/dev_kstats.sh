@@ -2,7 +2,7 @@
 # dev: per-kernel average duration of one bench run under rocprofv3 ($1 = tag, rest = env assignments / bench args)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$TAG -o ks -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$TAG -o ks -- python $R/bench.py --steps 20 --warmup 3 --ramp-steps 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2>&1
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$R/gpurun_out/ks_$TAG/ks_kernel_stats.csv")))

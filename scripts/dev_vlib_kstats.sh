@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; KERN=$1; shift; ARGS=$1; shift
 for t in "$@"; do
-  WN_LIB_PATH=$R/vlibs/lib_$t.so rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/vk_$t -o ks -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $ARGS > /dev/null 2>&1
+  WN_LIB_PATH=$R/vlibs/lib_$t.so rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/vk_$t -o ks -- python $R/bench.py --steps 20 --warmup 3 --ramp-steps 0 --no-cpu-baseline --no-extras $ARGS > /dev/null 2>&1
   python - <<PY
 import csv
 rows = list(csv.DictReader(open("$R/gpurun_out/vk_$t/ks_kernel_stats.csv")))

@@ -42,6 +42,13 @@ def key_of(name):
         return base + targs.replace(' ', '')
     if base in ('deconv_mfma_h_kernel', 'deconv_mfma_hs_kernel'):
         return base + targs.replace(' ', '')
+    if base == 'iaf_layer_kernel':       # fp32 form, template <HOIST, LAST>: hoisted conditioning / the flow head in the epilogue
+        a = [x.strip() for x in targs.strip('<>').split(',')]
+        tag = ','.join(t for t, on in (('hoist', a[0] == 'true'), ('head', len(a) > 1 and a[1] == 'true')) if on)
+        return base + ('<' + tag + '>' if tag else '')
+    if base == 'gemm_f32_kernel':        # template <NB, DECONV>: the conditioning GEMM / the upsampler's last layer
+        a = [x.strip() for x in targs.strip('<>').split(',')]
+        return base + ('<deconv>' if len(a) > 1 and a[1] == 'true' else '<cond>')
     return base
 
 
@@ -49,7 +56,7 @@ for sub in ('sq', 'fetch', 'write', 'inst'):
     for f in glob.glob(os.path.join(src, sub, '*counter_collection.csv')):
         for row in csv.DictReader(open(f)):
             k = key_of(row['Kernel_Name'])
-            if k is None or not (k.startswith('iaf_') or k.startswith('deconv_')):
+            if k is None or not (k.startswith('iaf_') or k.startswith('deconv_') or k.startswith('gemm_f32')):
                 continue
             agg[k][row['Counter_Name']] += float(row['Counter_Value'])
             cnt[(k, row['Counter_Name'])] += 1
@@ -75,7 +82,7 @@ if stats_csv:
 out = {
     '_about': 'rocprofv3 --pmc passes (scripts/pmc_layer.sh: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass, instruction-mix '
               'pass; kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ' + extra + '`, one MI355X, '
-              'split-fp16 (f16x3) path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
+              + ('fp32-MFMA' if 'f32' in extra else 'split-fp16 (f16x3)') + ' path. Per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB; '
               'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a coalesced '
               'stream, MI355X_MICROARCH.md; calibrated on iaf_head_h_kernel: it reads 98.3 MB exactly once and reports '
               '~48.8 MB). These fabric-side counters include Infinity Cache hits.',
