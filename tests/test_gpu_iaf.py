@@ -438,6 +438,53 @@ def test_phase_group_upsampler_matches_the_phase_major_form(monkeypatch):
             e.close()
 
 
+def test_fp32_forms_hoisted_against_fused_and_the_frame_axis_upsampler_against_the_phase_major_one(monkeypatch):
+    """The reference-precision (fp32-MFMA) arithmetic in its two placements of the conditioning 1x1s -- hoisted into one fp32
+    GEMM per deconv stack with the layer kernels on Q4 rows and the flow head in the last layer's epilogue (the default since
+    round 6) against one kernel per layer that reads enc itself -- and the upsampler's last layer as a frame-axis GEMM with the
+    input tile in LDS (gemm_f32_kernel<4, true>) against the phase-major GEMM of rounds 1-5 (WN_DC_NO_PG=1 at engine
+    creation): the same fp32 products summed in another order -> fp32-rounding level against each other, 2e-5 of the range
+    against the float64 oracle.  Shapes: one tile, ragged frame counts (the GEMM's last tile, the crop), several utterances,
+    a length that is a multiple of 64 but not of 128 samples (the hoisted form steps aside), private stacks (11- and
+    31-row-block GEMMs: task ranges that are not whole octets), tanh activation."""
+    from oracle import wavenet_np as O
+    rs = np.random.RandomState(92)
+    for extra, shapes in (({}, ((1, 8), (2, 35), (1, 71), (3, 129), (1, 384))),
+                          ({'num_stages': 7, 'num_iaf_layers': [7, 14]}, ((2, 9), (1, 24))),          # T % 128 == 64 at F = 24
+                          ({'upsample_act': 'tanh', 'use_share_deconv': False, 'num_iaf_layers': [10, 10, 10, 30]}, ((2, 21), (1, 66)))):
+        cfgd = dict(load_json('parallel_wavenet.json'), **extra)
+        hp = O.HP(cfgd)
+        w = O.synth_weights(hp, 'student', seed=778, init='tf')
+        monkeypatch.delenv('WN_DC_NO_PG', raising=False)
+        engs = {p: _engine(cfgd, w, p) for p in ('f32', 'f32-fused')}
+        monkeypatch.setenv('WN_DC_NO_PG', '1')
+        engs['f32, phase-major upsampler'] = _engine(cfgd, w, 'f32')
+        monkeypatch.delenv('WN_DC_NO_PG', raising=False)
+        for B, F in shapes:
+            T = O.iaf_length(F, hp)
+            if T == 0:
+                continue
+            assert engs['f32'].iaf_cond_hoisted(B, F) == (T % 128 == 0) and not engs['f32-fused'].iaf_cond_hoisted(B, F)
+            mel = rs.uniform(0, 1, [B, F, 80]).astype(np.float32)
+            noise = O.logistic_from_uniform(rs.uniform(1e-5, 1 - 1e-5, [B, T]))
+            out = {p: {k: _np(v) for k, v in e.iaf_generate(mel, noise, want=('x', 'mean_tot', 'scale_tot')).items()} for p, e in engs.items()}
+            base = out['f32-fused']
+            scale = max(1.0, np.abs(base['x']).max())
+            for p in ('f32', 'f32, phase-major upsampler'):
+                assert np.isfinite(out[p]['x']).all(), (extra, B, F, p)
+                for k in ('x', 'mean_tot', 'scale_tot'):
+                    assert np.abs(out[p][k] - base[k]).max() <= 6e-6 * scale, (extra, B, F, p, k)
+            enc = {p: _np(e.deconv(mel)) for p, e in engs.items() if p != 'f32-fused'}
+            assert np.abs(enc['f32'] - enc['f32, phase-major upsampler']).max() <= 2e-6 * max(1.0, np.abs(enc['f32']).max())
+            if F <= 71:
+                ref = O.iaf_feed_forward(mel, noise, w, hp, np.float64)
+                assert np.abs(out['f32']['x'] - ref['x']).max() <= 2e-5 * max(1.0, np.abs(ref['x']).max()), (extra, B, F)
+                enc_ref = O.deconv_stack(mel, w, hp, 'iaf_share' if cfgd.get('use_share_deconv', False) else 'iaf_1', np.float64)
+                assert np.abs(enc['f32'] - enc_ref).max() <= 2e-5 * max(1.0, np.abs(enc_ref).max())
+        for e in engs.values():
+            e.close()
+
+
 def test_part_timing_aid_accounts_for_the_call_and_leaves_results_alone():
     """wn_profile_parts_*: HIP events where the parts of a generate call begin (bench.py's in-process kernel_us_per_call).  The
     four parts of the default form are all present, non-negative and add up to about the wall time of the calls; the

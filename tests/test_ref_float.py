@@ -258,6 +258,27 @@ def test_oracle_equals_the_reference_code_at_full_size(RF):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['f32', 'f32-fused'])
+def test_fp32_engine_equals_the_reference_code_at_full_size(RF, precision):
+    """The headline configuration in the reference's own arithmetic (fp32 MFMA; `roofline_f32` of the bench line), hoisted form
+    (round 6: conditioning GEMM, Q4 rows, head in the last layer's epilogue) and fused form, against the reference's code."""
+    from nsynth_wavenet_amd.engine import Engine
+    g, cfgd, w = _case(RF, 'full')
+    eng = Engine(cfgd, precision=precision).load_weights(w)
+    assert eng.iaf_cond_hoisted(1, 384) is (precision == 'f32')
+    noise = _full_noise()
+    out = eng.iaf_generate(g['mel'], noise.astype(np.float32), want=('idx', 'x', 'scale_tot'))
+    x_ref = RF['full/x_f64']
+    err = float(np.abs(_np(out['x']) - x_ref).max())
+    assert err <= 2e-5 * max(1.0, float(np.abs(x_ref).max()))
+    assert np.abs(_np(out['scale_tot']) - RF['full/scale_tot_f32'].astype(np.float64)).max() <= 2e-5
+    di = np.abs(_np(out['idx']).astype(np.int64) - RF['full/idx_i16'].astype(np.int64))
+    assert di.max() <= 1 and (di != 0).mean() < 0.02
+    print('full size, {}: max|x - reference code| = {:.2e}; {} of {} indices one step off'.format(precision, err, int((di != 0).sum()), di.size))
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('groups', [1, -1])
 def test_engine_equals_the_reference_code_at_full_size(RF, groups):
     """The headline configuration on the default arithmetic, layer groups in LDS (what bench.py times) and per-layer
