@@ -36,6 +36,7 @@ class Engine(object):
         self._is_fork = False
         self._ws = None
         self._ar_stream = None
+        self._ar_groups = None              # per-group streams / queue states of ar_generate(streams=G)
         self._last_ws = None
         self.range_fallbacks = 0          # calls re-run on the fp32 form because they left the fp16 range
         self._finalized = False
@@ -73,6 +74,7 @@ class Engine(object):
         f = copy.copy(self)                 # same _hbox / _shared objects, same hparams
         f._is_fork = True
         f._ws = f._last_ws = f._ar_stream = None
+        f._ar_groups = None
         f.range_fallbacks = 0
         return f
 
@@ -437,7 +439,7 @@ class Engine(object):
     def _ar_generate_streams(self, enc, rnd, seed, forced, want_out, G):
         B, Tn = int(enc.shape[0]), int(enc.shape[1])
         ow = cfg.teacher_out_width(self.hp)
-        if not hasattr(self, '_ar_groups') or self._ar_groups is None or len(self._ar_groups) < G:
+        if self._ar_groups is None or len(self._ar_groups) < G:
             self._ar_groups = [{'stream': torch.cuda.Stream(self.device), 'ws': None} for _ in range(G)]
         bounds = [B * g // G for g in range(G + 1)]
         parts = []
