@@ -201,9 +201,10 @@ __device__ inline f4 buf_ld16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+template <int AUX = 0>
 __device__ inline void buf_st16(f4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u4_t w = __builtin_bit_cast(u4_t, v);
-    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, AUX);
     asm volatile("s_nop 1" ::"v"(w));
 }
 
@@ -296,6 +297,14 @@ struct HeadF {
 #define WN_F32_NH 2
 #endif
 constexpr int iaf_layer_threads(bool hoist) { return hoist ? 256 * WN_F32_NH : 256; }
+// Cache policy of the hoisted form's residual-stream stores: 16 = sc1, written through.  A launch writes 19.7 MB per
+// utterance that the NEXT launch reads from every XCD: left dirty in the L2s they are flushed at the kernel boundary, with
+// the matrix pipes idle (timing-only ablation: a launch without its stores is 2.65 us shorter); written through as they are
+// produced the launch is 1.9 us shorter (25.96 -> 24.03 us under rocprofv3; 3.21 -> 3.07 ms per call, A/B on one box).  The
+// same policy on the f16x3 group kernels (WN_G_ST_AUX) costs 4.5 %: their stores are a burst at the end of a long launch.
+#ifndef WN_F32_ST_AUX
+#define WN_F32_ST_AUX 16
+#endif
 
 template <bool HOIST, bool LAST = false>
 __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             if (HOIST) {                                   // channels 16 mb + 4 q + (0..3) = one word of group row 4 mb + q
-                buf_st16(d2[mb], ro, vo_out, 4 * mb * RS4);
+                buf_st16<WN_F32_ST_AUX>(d2[mb], ro, vo_out, 4 * mb * RS4);
                 continue;
             }
 #pragma unroll

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_kernel(const GfArgs A) {
     extern __shared__ __attribute__((aligned(16))) float ldsf[];
     constexpr int NC = 16 * NB;                                   // columns of a tile
     constexpr int PITCH = DECONV ? NC + 2 * GF_HALO : NC;         // floats per LDS row (one input channel)
-    constexpr int QUADS = PITCH / 4;                              // 16-byte pieces per row
-    constexpr int NQ = GF_CIN * QUADS;                            // ... per tile
-    constexpr int NST = (NQ + GF_THREADS - 1) / GF_THREADS;       // staging loads per thread
+    constexpr int QUADS = PITCH / 4;                              // column quads per row
+    constexpr int NI = (GF_CIN / 4) * QUADS;                      // staging items per tile: (channel group of 4) x (column quad)
+    constexpr int NST = (NI + GF_THREADS - 1) / GF_THREADS;       // ... per thread
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, q = lane >> 4;
 
@@ -106,19 +106,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_kernel(const GfArgs A) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(A.src + (size_t)b * A.src_bstride), 0, GF_CIN * A.src_rs * 4, 0x00020000);
             const int col0 = A.src_col0 + NC * jt;
-            f4 tmp[NST];
+            // LDS layout [K4 group][column][4]: the four input channels one lane multiplies in the four K-steps of a K-group
+            // side by side -- ONE ds_read_b128 per 16 MFMAs in the inner loop.  Group g holds channels 4 g + (0..3) of the
+            // student packs (K-step jj <-> channel 16 cg + 4 q + jj) / channels 16 (g / 4) + 4 (0..3) + g % 4 of the
+            // upsampler pack (16 cg + 4 jj + q).  An item = four rows x four columns, transposed in registers.
+            f4 tmp[NST][4];
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
                 const int i = k * GF_THREADS + (int)threadIdx.x;
-                const int row = i / QUADS, qd = i - row * QUADS;
-                tmp[k] = (f4){0.f, 0.f, 0.f, 0.f};
-                if (i < NQ) tmp[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (row * A.src_rs + col0 + 4 * qd) * 4, 0, 0));
+                const int grp = i / QUADS, qd = i - grp * QUADS;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ch = DECONV ? 16 * (grp >> 2) + 4 * c + (grp & 3) : 4 * grp + c;
+                    tmp[k][c] = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (i < NI) tmp[k][c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ch * A.src_rs + col0 + 4 * qd) * 4, 0, 0));
+                }
             }
             __syncthreads();                      // the previous tile's operand reads are done
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
                 const int i = k * GF_THREADS + (int)threadIdx.x;
-                if (i < NQ) *reinterpret_cast<f4*>(ldsf + (size_t)i * 4) = tmp[k];
+                const int grp = i / QUADS, qd = i - grp * QUADS;
+                if (i < NI) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<f4*>(ldsf + (size_t)((grp * PITCH + 4 * qd + e) * 4)) =
+                            (f4){tmp[k][0][e], tmp[k][1][e], tmp[k][2][e], tmp[k][3][e]};
+                }
             }
             __syncthreads();
         }
@@ -143,35 +157,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_kernel(const GfArgs A) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     a[p][mb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, p * ks4, 0));
-            // one K-group: 16 input channels x the tile's NB column blocks = 16 NB MFMAs
+            // one K-group: 16 input channels x the tile's NB column blocks = 16 NB MFMAs.  K-step jj of the group multiplies
+            // channel 16 cg + 4 q + jj (the student packs, wn_pack_iaf) or 16 cg + 4 jj + q (the upsampler pack,
+            // wn_pack_deconv) of lane group q: word jj of LDS group 4 cg + q; tap j = kg / 16 of the deconv reads x[f + d - j]
+            auto brow_of = [&](int kg) -> const f4* {
+                const int colb = DECONV ? GF_HALO + dshift - (kg >> 4) : 0;
+                return reinterpret_cast<const f4*>(ldsf) + (4 * (kg & 15) + q) * PITCH + colb + n;
+            };
+            f4 bwn = brow_of(0)[0];               // operand word of the NEXT column block, one block (16 MFMAs) ahead of its use
             auto kgroup = [&](int kg, auto cur_c) {
                 constexpr int cur = decltype(cur_c)::value;
-                if (kg + NBUF - 1 < A.nkg) {
+                {
+                    // UNCONDITIONAL (the last NBUF - 1 groups reload the task's last fragments): behind a branch the compiler
+                    // cannot count the loads in flight and waits for ALL of them -- the ones just issued included -- before the
+                    // group's first MFMA (s_waitcnt vmcnt(0) where vmcnt(4 (NBUF - 1)) is meant): an L2 round trip per K-group
+                    const int kn = min(kg + NBUF - 1, A.nkg - 1);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         a[(cur + NBUF - 1) % NBUF][mb] =
-                            __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, (kg + NBUF - 1) * ks4, 0));
+                            __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, ao + mb * 1024, kn * ks4, 0));
                 }
-                const int cg = kg & 15;                           // channel group of 16
-                const int colb = DECONV ? GF_HALO + dshift - (kg >> 4) : 0;   // tap j = kg / 16 reads x[f + d - j]
-                // K-step jj of the group multiplies channel 16 cg + 4 q + jj (the student packs, wn_pack_iaf) or
-                // 16 cg + 4 jj + q (the upsampler pack, wn_pack_deconv) of lane group q
-                constexpr int QS = DECONV ? 1 : 4, JS = DECONV ? 4 : 1;
-                const float* brow = ldsf + (16 * cg + QS * q) * PITCH + colb + n;
-                float bw[2][4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bw[0][jj] = brow[jj * JS * PITCH];
+                // ... and pinned at the head of the group (left alone the scheduler sinks them to their first use)
+                __builtin_amdgcn_sched_barrier(0);
+                const f4* brow = brow_of(kg);
+                const f4* brow1 = brow_of(min(kg + 1, A.nkg - 1));
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (nb + 1 < NB) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) bw[(nb + 1) & 1][jj] = brow[jj * JS * PITCH + 16 * (nb + 1)];
-                    }
+                    const f4 bw = bwn;
+                    bwn = nb + 1 < NB ? brow[16 * (nb + 1)] : brow1[0];
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma4(a[cur][mb][jj], bw[nb & 1][jj], acc[mb][nb]);
+                        for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = mfma4(a[cur][mb][jj], bw[jj], acc[mb][nb]);
+                    // the next column block's operand word first (ds_read_b128), then this block's 16 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             };
             for (int kg = 0; kg < A.nkg; kg += NBUF) {            // (nkg is a multiple of 16)
                 kgroup(kg, std::integral_constant<int, 0>{});

@@ -344,8 +344,8 @@ __global__ __launch_bounds__(GK_THREADS, 1) void iaf_group_kernel(const GArgs A)
                     const int vo = q * RS16 + col * 16;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        buf_st4(oh[e][s2], ro, vo, (4 * s2) * RS16);
-                        buf_st4(ol[e][s2], ro, vo, (8 + 4 * s2) * RS16);
+                        buf_st4<WN_G_ST_AUX>(oh[e][s2], ro, vo, (4 * s2) * RS16);
+                        buf_st4<WN_G_ST_AUX>(ol[e][s2], ro, vo, (8 + 4 * s2) * RS16);
                     }
                 }
                 continue;

@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256, 1) void iaf_layer_h_kernel(
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                buf_st4(oh[s2], ro, vo_out + 16 * e, (4 * s2) * RS16);
-                buf_st4(ol[s2], ro, vo_out + 16 * e, (8 + 4 * s2) * RS16);
+                buf_st4<WN_G_ST_AUX>(oh[s2], ro, vo_out + 16 * e, (4 * s2) * RS16);
+                buf_st4<WN_G_ST_AUX>(ol[s2], ro, vo_out + 16 * e, (8 + 4 * s2) * RS16);
             }
         }
     }

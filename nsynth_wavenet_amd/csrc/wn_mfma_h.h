@@ -132,6 +132,9 @@ __device__ inline wn_u4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 // write them -- and holds two wait states.  It lives HERE, in the one helper every such store goes through (round 3 had
 // it at the call sites: the next new call site would have been unguarded).  scripts/audit_store_hazard.py (run by
 // tests/test_host.py) still reads the compiler's assembly of every kernel for the pattern.
+#ifndef WN_G_ST_AUX
+#define WN_G_ST_AUX 0
+#endif
 template <int AUX = 0>
 __device__ inline void buf_st4(wn_u4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);
