@@ -938,7 +938,13 @@ void wn_ar_release(wn_handle* h) {
 }
 
 // entries whose stream has finished replaying them
+// Process-wide: held while a thread captures AND while finished graphs are retired -- hipEventQuery on an event last recorded
+// in a stream that another thread is capturing on is refused by the runtime and invalidates that capture (the `done` events of
+// every caller's graphs hang off the shared handle).
+static std::mutex g_capture_mu;
+
 static void ar_retire_finished(wn_handle* h) {
+    std::lock_guard<std::mutex> cap(g_capture_mu);
     std::vector<void*> gone;
     {
         std::lock_guard<std::mutex> g(h->list_mu);
@@ -1188,24 +1194,47 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     ar_retire_finished(h);
     ArGraphCache* gc = new ArGraphCache();
     gc->stream = st;
-    auto capture = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-            (void)hipGetLastError();
+    // Captures are serialised across the threads of the process (the handle may be shared; g_capture_mu), and a
+    // capture that has been invalidated -- by a device-wide call of some other thread, say -- is ENDED until
+    // hipStreamIsCapturing reports none: otherwise every later launch on the stream fails with
+    // hipErrorStreamCaptureInvalidated, the plain-launch fallback included (seen once in ~25 two-thread calls on ROCm 7.2).
+    static const bool dbg = getenv("WN_AR_DEBUG") != nullptr;
+    auto leave_capture = [&]() {
+        for (int k = 0; k < 4; ++k) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) break;
+            hipGraph_t junk = nullptr;
+            (void)hipStreamEndCapture(st, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+        }
+        (void)hipGetLastError();
+    };
+    auto capture_once = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
+        std::lock_guard<std::mutex> lk(g_capture_mu);
+        const hipError_t e0 = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e0 != hipSuccess) {
+            if (dbg) fprintf(stderr, "wn_ar_generate: begin capture failed: %s\n", hipGetErrorString(e0));
+            leave_capture();
             return false;
         }
         for (int i = 0; i < nsteps; ++i)
             ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
         const hipError_t e1 = hipGetLastError();
         const hipError_t e2 = hipStreamEndCapture(st, g);            // always: leaves capture mode
-        if (e1 != hipSuccess || e2 != hipSuccess || !*g ||
-            hipGraphInstantiate(ex, *g, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
+        hipError_t e3 = hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess || !*g || (e3 = hipGraphInstantiate(ex, *g, nullptr, nullptr, 0)) != hipSuccess) {
+            if (dbg) fprintf(stderr, "wn_ar_generate: capture failed: launches %s, end %s, instantiate %s\n",
+                             hipGetErrorString(e1), hipGetErrorString(e2), hipGetErrorString(e3));
             if (*g) (void)hipGraphDestroy(*g);
             *g = nullptr;
             *ex = nullptr;
+            leave_capture();
             return false;
         }
         return true;
+    };
+    auto capture = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
+        return capture_once(nsteps, g, ex) || capture_once(nsteps, g, ex);     // (another thread's device-wide call can still invalidate one)
     };
     const int multi = Tn / AR_GRAPH_STEPS, rest = Tn % AR_GRAPH_STEPS;
     bool ok = true;

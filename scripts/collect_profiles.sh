@@ -18,6 +18,7 @@ cp $G/finl/finl_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_per_layer_laun
 cp $G/fin8/fin8_kernel_stats.csv profiles/${R}_kernel_stats_f16x3_batch8.csv
 cp $G/fin32/fin32_kernel_stats.csv profiles/${R}_kernel_stats_f32.csv
 [ -f $G/mfma_f32_power.txt ] && cp $G/mfma_f32_power.txt profiles/${R}_mfma_f32_power_ubench.txt
+[ -f $G/mfma_f32_issue.txt ] && cp $G/mfma_f32_issue.txt profiles/${R}_mfma_f32_issue_ubench.txt
 cp $G/power_per_part.txt profiles/${R}_power_per_part.txt
 [ -f $G/mfma_power.txt ] && cp $G/mfma_power.txt profiles/${R}_mfma_power_ubench_final.txt
 cp $G/ramp.txt profiles/${R}_clock_ramp.txt

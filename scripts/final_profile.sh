@@ -30,6 +30,7 @@ python scripts/dev_power.py --batch 8 --seconds 2 2>&1 | grep -v amdgpu.ids | te
 HW=$(grep -m1 "^hwmon" gpurun_out/power_per_part.txt | awk '{print $2}')
 [ -x scripts/ubench/mfma_power ] && scripts/ubench/mfma_power $HW 3 | tee gpurun_out/mfma_power.txt
 [ -x scripts/ubench/mfma_f32_power ] && timeout 120 scripts/ubench/mfma_f32_power auto 2.5 | tee gpurun_out/mfma_f32_power.txt
+(cd scripts/ubench && timeout 200 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o /tmp/mfma_f32_issue mfma_f32_issue.hip && timeout 120 /tmp/mfma_f32_issue) | tee gpurun_out/mfma_f32_issue.txt
 python scripts/dev_ramp.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ramp.txt
 # batch sweep of the two launch structures (policy of wn_iaf_use_groups): ms per call
 for b in 1 2 4 6 8 12 16; do

@@ -185,12 +185,12 @@ def test_one_teacher_handle_two_threads_two_streams(use_graph):
             with torch.cuda.stream(st):
                 for _ in range(4):
                     got.append(f.ar_generate(cases[i][0], cases[i][1], want_out=True, use_graph=use_graph))
-            st.synchronize()
-            torch.cuda.synchronize()
-            f.close()
+            st.synchronize()             # (its own stream only: ROCm refuses a device-wide synchronise while ANY thread is
+            f.close()                    #  capturing, thread-local capture mode or not, and invalidates that capture)
             return got
         return run
     outs = _run_threads([worker(0), worker(1)])
+    torch.cuda.synchronize()
     for i in range(2):
         for o in outs[i]:
             for k in ('idx', 'wav', 'out_params'):
