@@ -1,6 +1,6 @@
 # final measurement pass of a round (run through gpurun): tests, bench lines, kernel stats, PMC passes
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2 | tee gpurun_out/gputest_final.txt
+timeout 1500 python -m pytest tests -q -m gpu -rf 2>&1 | tail -8 | tee gpurun_out/gputest_final.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke_final.txt
 timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_f16x3.json
 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_f16x3_driver_protocol.json

@@ -15,7 +15,10 @@ bad = 0
 t_end = time.time() + budget / 2
 d = json.load(open(os.path.join(ROOT, 'config_jsons', 'parallel_wavenet.json')))
 hp = cfg.load_hparams(d)
-w = wts.synthetic_weights(hp, seed=int(rs.randint(1 << 20)), init='unit' if rs.rand() < 0.5 else 'tf')
+init = os.environ.get('WN_FUZZ_INIT') or ('unit' if rs.rand() < 0.5 else 'tf')
+wseed = int(rs.randint(1 << 20))
+print('student weights: init', init, 'seed', wseed, flush=True)
+w = wts.synthetic_weights(hp, seed=wseed, init=init)
 FORMS = ('f16x3-fused', 'f16x3-hoisted', 'f32', 'f32-fused')
 engs = {p: Engine(d, precision=p).load_weights(w) for p in ('f16x3',) + FORMS}
 os.environ['WN_DC_NO_PG'] = '1'           # (read once, in wn_create) the upsampler's last layer as phase-major GEMM + interleave
@@ -46,7 +49,10 @@ while time.time() < t_end:
         engs['f16x3-hoisted'].set_layer_groups(None)
         e = float((x - a['x']).abs().max())
         errs[tag] = e if e == e else float('inf')
-    tol = max(2e-5 * scale, 3.0 * errs['f32'])
+    # (round 6: 2e-5 * scale was marginal -- unit-gain weights amplify the forms' different summation orders to 2e-6 .. 8e-5 of
+    # max|x| depending on the draw, scripts/dev_fuzz_repro.py: every form deterministic, pairwise 2e-6 .. 9e-6 on the cases that
+    # tripped it.  A race moves samples by their own size; and every tenth case now runs each form twice, bit for bit.)
+    tol = max(3e-4 * scale, 3.0 * errs['f32'])
     worst, ok = 0.0, errs['f32'] <= 1e-4 * scale
     for p in errs:
         if p != 'f32':
@@ -54,6 +60,13 @@ while time.time() < t_end:
             if not errs[p] <= tol:
                 ok = False
                 print('  form', p, 'differs by', errs[p], '(fp32 form: %.3g)' % errs['f32'], flush=True)
+    if n % 10 == 0:
+        for p in FORMS:
+            x1 = engs[p].iaf_generate(mel, a['rand_input'], want=('x',))['x'].clone()
+            x2 = engs[p].iaf_generate(mel, a['rand_input'], want=('x',))['x']
+            if not torch.equal(x1, x2):
+                ok = False
+                print('  form', p, 'is NOT deterministic:', float((x1 - x2).abs().max()), flush=True)
     ok = ok and k2 <= 2e-6 * scale and bool(torch.isfinite(a['x']).all())
     bad += not ok
     n += 1
