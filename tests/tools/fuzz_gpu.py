@@ -53,7 +53,7 @@ while time.time() < t_end:
     # max|x| depending on the draw, scripts/dev_fuzz_repro.py: every form deterministic, pairwise 2e-6 .. 9e-6 on the cases that
     # tripped it.  A race moves samples by their own size; and every tenth case now runs each form twice, bit for bit.)
     tol = max(3e-4 * scale, 3.0 * errs['f32'])
-    worst, ok = 0.0, errs['f32'] <= 1e-4 * scale
+    worst, ok = 0.0, errs['f32'] <= 3e-4 * scale
     for p in errs:
         if p != 'f32':
             worst = max(worst, errs[p])
