@@ -291,8 +291,9 @@ WN_API int wn_ar_cond_vars(wn_handle* h, const float* enc, int B, int Tn, float*
 
 /* wn_ar_generate replays the step from a hipGraph (16 steps per graph) when the caller's stream can be
  * captured (any stream but the legacy null stream); enable = 0 makes it issue plain launches instead
- * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  A failed capture falls back to
- * plain launches by itself and never leaves the caller's stream in capture mode. */
+ * (A/B measurements, graph-vs-launch parity tests).  Default: enabled.  The steps are captured on a private
+ * stream of the handle and replayed on the caller's, which is never in capture mode; a capture that fails or is
+ * invalidated from outside (a device-wide synchronise of another thread) falls back to plain launches by itself. */
 WN_API int wn_ar_set_graph(wn_handle* h, int enable);
 
 /* Full-sequence teacher forward, `Wavenet.feed_forward` (wavenet/wavenet.py:180-291) for a teacher

@@ -928,6 +928,11 @@ void ar_cache_free(ArGraphCache* c) {
 
 }  // namespace
 
+// Process-wide: held while a thread captures AND while finished graphs are retired -- hipEventQuery on an event last recorded
+// in a stream that another thread is capturing on is refused by the runtime and invalidates that capture (the `done` events of
+// every caller's graphs hang off the shared handle).
+static std::mutex g_capture_mu;
+
 void wn_ar_release(wn_handle* h) {
     std::vector<void*> all;
     {
@@ -935,13 +940,13 @@ void wn_ar_release(wn_handle* h) {
         all.swap(h->ar_graphs);
     }
     for (void* p : all) ar_cache_free(reinterpret_cast<ArGraphCache*>(p));
+    std::lock_guard<std::mutex> cap(g_capture_mu);
+    if (h->ar_cap_stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(h->ar_cap_stream));
+    h->ar_cap_stream = nullptr;
+    (void)hipGetLastError();
 }
 
 // entries whose stream has finished replaying them
-// Process-wide: held while a thread captures AND while finished graphs are retired -- hipEventQuery on an event last recorded
-// in a stream that another thread is capturing on is refused by the runtime and invalidates that capture (the `done` events of
-// every caller's graphs hang off the shared handle).
-static std::mutex g_capture_mu;
 
 static void ar_retire_finished(wn_handle* h) {
     std::lock_guard<std::mutex> cap(g_capture_mu);
@@ -1188,39 +1193,44 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
     const char* eg = getenv("WN_AR_GRAPH");
     if (!st || !use_graph || (eg && eg[0] == '0')) return plain(Tn);
     // Every per-step address is derived on the device from the step counter, so a captured step is static:
-    // build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay.  A failed capture is always closed (the
-    // caller's stream must not be left in capture mode), its partial graph destroyed, and the call falls
-    // back to plain launches.
+    // build (AR_GRAPH_STEPS steps) + (1 step) graphs and replay them on the caller's stream.
+    // The steps are captured on a PRIVATE non-blocking stream of the handle, never on the caller's: a capture can be
+    // invalidated from outside -- on ROCm 7.2 a device-wide synchronise of ANY thread does it, thread-local capture mode or
+    // not -- and the runtime then leaves that stream unusable for good (status "invalidated"; hipStreamEndCapture answers
+    // "attempt to terminate a thread-local capture sequence from another thread" to the thread that began it, every later launch
+    // on the stream fails).  Lost that way, the private stream is dropped and replaced, and the call falls back to plain launches
+    // on the caller's stream, which was never in capture mode.  (A non-blocking stream also keeps legacy-stream work of
+    // other threads legal during the capture.)  Captures and the retiring of finished graphs are serialised by g_capture_mu.
     ar_retire_finished(h);
     ArGraphCache* gc = new ArGraphCache();
     gc->stream = st;
-    // Captures are serialised across the threads of the process (the handle may be shared; g_capture_mu), and a
-    // capture that has been invalidated -- by a device-wide call of some other thread, say -- is ENDED until
-    // hipStreamIsCapturing reports none: otherwise every later launch on the stream fails with
-    // hipErrorStreamCaptureInvalidated, the plain-launch fallback included (seen once in ~25 two-thread calls on ROCm 7.2).
     static const bool dbg = getenv("WN_AR_DEBUG") != nullptr;
-    auto leave_capture = [&]() {
-        for (int k = 0; k < 4; ++k) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) break;
-            hipGraph_t junk = nullptr;
-            (void)hipStreamEndCapture(st, &junk);
-            if (junk) (void)hipGraphDestroy(junk);
-        }
-        (void)hipGetLastError();
-    };
     auto capture_once = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
         std::lock_guard<std::mutex> lk(g_capture_mu);
-        const hipError_t e0 = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (!h->ar_cap_stream) {
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            h->ar_cap_stream = cs;
+        }
+        hipStream_t cap = reinterpret_cast<hipStream_t>(h->ar_cap_stream);
+        auto drop_stream = [&]() {               // (destroying an invalidated stream may fail too: then it is leaked, once)
+            (void)hipStreamDestroy(cap);
+            h->ar_cap_stream = nullptr;
+            (void)hipGetLastError();
+        };
+        const hipError_t e0 = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
         if (e0 != hipSuccess) {
             if (dbg) fprintf(stderr, "wn_ar_generate: begin capture failed: %s\n", hipGetErrorString(e0));
-            leave_capture();
+            drop_stream();
             return false;
         }
         for (int i = 0; i < nsteps; ++i)
-            ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, st);
+            ar_enqueue_step(h, state, B, nullptr, forced_wav, enc, Tn, 0, rnd, seed, idx, wav, out_params, cap);
         const hipError_t e1 = hipGetLastError();
-        const hipError_t e2 = hipStreamEndCapture(st, g);            // always: leaves capture mode
+        const hipError_t e2 = hipStreamEndCapture(cap, g);
         hipError_t e3 = hipSuccess;
         if (e1 != hipSuccess || e2 != hipSuccess || !*g || (e3 = hipGraphInstantiate(ex, *g, nullptr, nullptr, 0)) != hipSuccess) {
             if (dbg) fprintf(stderr, "wn_ar_generate: capture failed: launches %s, end %s, instantiate %s\n",
@@ -1228,13 +1238,13 @@ extern "C" int wn_ar_generate(wn_handle* h, const float* enc, int B, int Tn, con
             if (*g) (void)hipGraphDestroy(*g);
             *g = nullptr;
             *ex = nullptr;
-            leave_capture();
+            drop_stream();
             return false;
         }
         return true;
     };
     auto capture = [&](int nsteps, hipGraph_t* g, hipGraphExec_t* ex) -> bool {
-        return capture_once(nsteps, g, ex) || capture_once(nsteps, g, ex);     // (another thread's device-wide call can still invalidate one)
+        return capture_once(nsteps, g, ex) || capture_once(nsteps, g, ex);     // (once more, on a fresh private stream)
     };
     const int multi = Tn / AR_GRAPH_STEPS, rest = Tn % AR_GRAPH_STEPS;
     bool ok = true;

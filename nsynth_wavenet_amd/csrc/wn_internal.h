@@ -173,6 +173,7 @@ struct wn_handle {
     // hipGraphs of the wn_ar_generate calls in flight (wn_ar.hip): one entry per call, retired by later calls once its
     // stream has run it, all released in wn_destroy
     std::vector<void*> ar_graphs;
+    void* ar_cap_stream = nullptr;     // private non-blocking stream wn_ar_generate CAPTURES on (wn_ar.hip; under its capture mutex)
     bool ar_use_graph = true;                 // wn_ar_set_graph
     // bench.py measurement aid (wn_profile_begin/end)
     bool prof_on = false;

@@ -198,6 +198,50 @@ def test_one_teacher_handle_two_threads_two_streams(use_graph):
     eng.close()
 
 
+def test_a_capture_lost_to_another_threads_device_synchronise_falls_back_to_plain_launches():
+    """ROCm 7.2 invalidates a stream capture when ANY thread synchronises the device and leaves the captured stream unusable
+    for good.  wn_ar_generate captures on a private stream of the handle, so what is lost is that stream: the call falls back
+    to plain launches on the caller's stream and every result still equals the serial call (scripts/dev_ar_capture_hammer.py:
+    180 calls, 357 lost captures, 0 wrong results)."""
+    import torch
+    from oracle import wavenet_np as O
+    from nsynth_wavenet_amd.engine import Engine
+    g = np.load(os.path.join(GOLD, 'ar_mol.npz'))
+    cfgd = json.loads(str(g['cfg_json']))
+    hp = O.HP(cfgd)
+    eng = Engine(cfgd).load_weights(O.synth_weights(hp, 'teacher', seed=1234, init='unit'))
+    enc, rnd = g['enc'], g['rnd']
+    eng._set_ar_graph(True)
+    serial = {k: v.clone() for k, v in eng.ar_generate(enc, rnd, want_out=True, use_graph=True).items()}
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def hammer():
+        while not stop.is_set():
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError:                 # refused by the runtime while the other thread captures: the hammer's problem
+                pass
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        f = eng.fork()
+        st = torch.cuda.Stream()
+        got = []
+        with torch.cuda.stream(st):
+            for _ in range(8):
+                got.append(f.ar_generate(enc, rnd, want_out=True, use_graph=True))
+        st.synchronize()
+    finally:
+        stop.set()
+        th.join()
+    f.close()
+    for o in got:
+        for k in ('idx', 'wav', 'out_params'):
+            assert torch.equal(o[k], serial[k]), k
+    eng.close()
+
+
 def test_ar_groups_on_streams_equal_the_single_stream_call(monkeypatch):
     """Engine.ar_generate(streams=G): G utterance groups as independent chains on G streams against one handle, injected
     randoms -- row for row the single-stream call (the batched MFMA step forced for every group size: the GEMV step small
