@@ -140,11 +140,33 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_kernel(const TgArgs a) {
 #pragma unroll
                 for (int e = 0; e < TG_NT; ++e) { vh[e] = b1h[e]; vl[e] = b1l[e]; }
                 if (ks + 1 < a.nks) loadB(ks + 1, b1h, b1l);
+#ifndef WN_TG_APIPE
+#define WN_TG_APIPE 1
+#endif
+                if (WN_TG_APIPE) {
+                    // weight fragments one row block (12 MFMAs) ahead of their use: read where they are used, each pair of
+                    // ds_read_b128 sat in front of its own MFMAs and the wave waited out the LDS latency twelve MFMAs at a time
+                    wn_u4 ahn = Al[(kl * 4 * U) * 128], aln = Al[(kl * 4 * U) * 128 + 64];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int mb = 0; mb < 4 * U; ++mb) {
+                        const wn_u4 ah = ahn, al = aln;
+                        if (mb + 1 < 4 * U) {
+                            ahn = Al[(kl * 4 * U + mb + 1) * 128];
+                            aln = Al[(kl * 4 * U + mb + 1) * 128 + 64];
+                        }
+#pragma unroll
+                        for (int e = 0; e < TG_NT; ++e) acc[mb][e] = mfma3(ah, al, vh[e], vl[e], acc[mb][e]);
+                        if (mb + 1 < 4 * U) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TG_NT, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int mb = 0; mb < 4 * U; ++mb) {
                     const wn_u4 ah = Al[(kl * 4 * U + mb) * 128], al = Al[(kl * 4 * U + mb) * 128 + 64];
 #pragma unroll
                     for (int e = 0; e < TG_NT; ++e) acc[mb][e] = mfma3(ah, al, vh[e], vl[e], acc[mb][e]);
+                }
                 }
             }
         }
