@@ -306,12 +306,23 @@ constexpr int iaf_layer_threads(bool hoist) { return hoist ? 256 * WN_F32_NH : 2
 #define WN_F32_ST_AUX 16
 #endif
 
-template <bool HOIST, bool LAST = false>
+// START (hoisted form): the layer opens a flow (dilation 1) and computes its own input instead of loading it -- l0 =
+// start_conv(shift_right(x)) (parallel_wavenet.py:222-225): l0[c][t'] = b[c] + w0[c] x[t'-3] + w1[c] x[t'-2] + w2[c] x[t'-1],
+// 0 left of the utterance -- from five x values per column and the lane's 16 x 4 coefficients held in registers: the flow's first
+// l is neither written (iaf_start_q4_kernel, a launch per flow) nor read back (12 of the block's 16 operand loads).
+struct StartF {
+    const float* x;          // flow input rows [B][XR], IAF_XP zero columns in front
+    const float* w;          // start conv: w0[64] | w1[64] | w2[64] | b[64]
+    int XR;
+};
+
+template <bool HOIST, bool LAST = false, bool START = false>
 __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
     const float* __restrict__ lin, float* __restrict__ lout, const float* __restrict__ enc,
     const float* __restrict__ wpack, int64_t RS, int64_t TE, int d, int tiles_per_row, int ntiles,
-    const float* __restrict__ C, int64_t c_bstride, const HeadF hd) {
+    const float* __restrict__ C, int64_t c_bstride, const HeadF hd, const StartF sf) {
     static_assert(HOIST || !LAST, "the head runs in the epilogue of the hoisted form only");
+    static_assert((HOIST && !LAST) || !START, "the start conv runs in front of a plain hoisted layer only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NG = HOIST ? 12 : 28;                 // K-groups of four K-steps
     constexpr int P_FLOATS = NG * 1024;
@@ -367,6 +378,40 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
         }
         return v;
     };
+    // START: the lane's coefficients (channels 16 cg + 4 q + jj) and the operand of K-group g (tap t - 2 + g / 4) from
+    // xv[j] = x[t - 5 + j]; the expression is iaf_start_q4_kernel's, term for term
+    f4 sw0[4], sw1[4], sw2[4], sbs[4];
+    if (START) {
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int c = 16 * cg + 4 * q + jj;
+                sw0[cg][jj] = sf.w[c];
+                sw1[cg][jj] = sf.w[IAF_W + c];
+                sw2[cg][jj] = sf.w[2 * IAF_W + c];
+                sbs[cg][jj] = sf.w[3 * IAF_W + c];
+            }
+    }
+    struct XV { float v[5]; int t; };
+    auto load_x = [&](int tile) -> XV {
+        const int b = tile / tiles_per_row;
+        const int t = (tile - b * tiles_per_row) * 64 + wave * 16 + n;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(sf.x + (size_t)b * sf.XR), 0, sf.XR * 4, 0x00020000);
+        XV r;
+        r.t = t;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) r.v[j] = buf_ld(rx, (IAF_XP + t - 5 + j) * 4, 0);
+        return r;
+    };
+    auto start_op = [&](const XV& xv, int g) -> f4 {
+        const int k = g >> 2, cg = g & 3;
+        f4 o;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            o[jj] = sbs[cg][jj] + sw0[cg][jj] * xv.v[k] + sw1[cg][jj] * xv.v[k + 1] + sw2[cg][jj] * xv.v[k + 2];
+        return xv.t - 2 + k >= 0 ? o : (f4){0.f, 0.f, 0.f, 0.f};
+    };
     // The f32 MFMA is slow (32 cycles per instruction per SIMD) and this kernel runs one wave
     // per SIMD, so memory latency is hidden by distance, not occupancy: as soon as K-group g of
     // tile i has been multiplied, the B operands of group g of the wave's NEXT tile are loaded
@@ -387,10 +432,17 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
             f_dma_image(hd.whead + IAF_PH_FLOATS, lds_base + (IAF_LAYER_F_FLOATS + 4 * 1024) * 4, 64 * 3 + 4, wv, lane, NWV);
         }
     }
+    XV xn{};
     if (tile0 < ntiles) {
         const TileSrc s0 = tile_src(tile0);
+        if (START) {
+            xn = load_x(tile0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) bcur[g] = loadB(s0, g);
+            for (int g = 0; g < NG; ++g) bcur[g] = start_op(xn, g);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bcur[g] = loadB(s0, g);
+        }
         if (HOIST) load_c(tile0, ccur);
         if (LAST) load_c(tile0, hcur, hd.Ch);
     }
@@ -414,6 +466,7 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[mb] = HOIST ? ccur[mb] : *reinterpret_cast<const f4*>(bg + mb * 4);
         if (HOIST && has_next) load_c(next, ccur);
+        if (START) xn = load_x(has_next ? next : tile);
         f4 hacc[4];
         if (LAST) {
 #pragma unroll
@@ -437,10 +490,17 @@ __global__ __launch_bounds__(iaf_layer_threads(HOIST), 1) void iaf_layer_kernel(
             // latency hides under this group's 16 MFMAs), then the MFMAs
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            if (has_next) bcur[g] = loadB(sn, g);
+            // START: the next tile's operands from its x values, four groups behind the loads issued at the top of this tile
+            // (their round trip) -- group g - 4 here, the last four behind the loop
+            if (START) { if (g >= 4) bcur[g - 4] = start_op(xn, g - 4); }
+            else if (has_next) bcur[g] = loadB(sn, g);
             // keep the schedule group-by-group: without this fence the scheduler hoists every
             // LDS weight read of the unrolled loop to the top and spills hundreds of registers
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (START) {
+#pragma unroll
+            for (int g = NG - 4; g < NG; ++g) bcur[g] = start_op(xn, g);
         }
         // gate: sigmoid(first half) * tanh(second half)  (parallel_wavenet.py:246-250)
         f4 gt[2];
@@ -1106,7 +1166,10 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
         // starts with such a pair the start conv runs inside it as well
         const bool pair_start = hoist && f16x3 && fp.layers.size() >= 2 && fp.layers[0].dilation == 1 &&
                                 wn_iaf_c_pair_ok(fp.layers[0].dilation, fp.layers[1].dilation);
-        if (fuse_start || pair_start) {
+        // fp32 hoisted form: the start conv runs in front of the first layer (dilation 1, at least two layers: the last one carries the head)
+        static const bool no_start_fuse = getenv("WN_F32_NO_STARTFUSE") != nullptr;
+        const bool start_in_layer = hoist && !f16x3 && !no_start_fuse && fp.layers.size() >= 2 && fp.layers[0].dilation == 1;
+        if (fuse_start || pair_start || start_in_layer) {
         } else if (f16x3) {
             wn_iaf_h_start(x, h->d_blob + fp.start_off, lA, L.T, L.XR, L.RS, B, st, status);
         } else if (hoist) {
@@ -1171,21 +1234,26 @@ extern "C" int wn_iaf_generate_form(wn_handle* h, int form, const float* mel, in
                 hipLaunchKernelGGL((iaf_layer_kernel<true, true>), dim3(grid), dim3(iaf_layer_threads(true)),
                                    (IAF_LAYER_F_FLOATS + IAF_HEAD_F_FLOATS) * sizeof(float), st, lin, lout, encc,
                                    h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row, ntiles, Cf + li * rb_floats,
-                                   L.c_bstride, hd);
+                                   L.c_bstride, hd, StartF{});
                 head_done = true;
                 ++li;
                 continue;
-            } else if (hoist)
+            } else if (hoist && i == 0 && start_in_layer)
+                // fp32 hoisted form, first layer of the flow: the start conv runs in front of it (iaf_layer_kernel<true, false, true>)
+                hipLaunchKernelGGL((iaf_layer_kernel<true, false, true>), dim3(grid), dim3(iaf_layer_threads(true)), IAF_LAYER_F_FLOATS * sizeof(float), st,
+                                   lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row, ntiles,
+                                   Cf + li * rb_floats, L.c_bstride, HeadF{}, StartF{x, h->d_blob + fp.start_off, L.XR});
+            else if (hoist)
                 hipLaunchKernelGGL((iaf_layer_kernel<true, false>), dim3(grid), dim3(iaf_layer_threads(true)), IAF_LAYER_F_FLOATS * sizeof(float), st,
                                    lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row, ntiles,
-                                   Cf + li * rb_floats, L.c_bstride, HeadF{});
+                                   Cf + li * rb_floats, L.c_bstride, HeadF{}, StartF{});
             else if (f16x3)
                 wn_iaf_h_layer(lin, lout, enc, h->d_blob + lp.off_h, L.RS, L.TE, L.c0, lp.dilation, B, L.T, h->num_cu, st, status,
                                (li == 0 && fuse_start) ? x : nullptr, L.XR, h->d_blob + fp.start_off);
             else
                 hipLaunchKernelGGL((iaf_layer_kernel<false, false>), dim3(grid), dim3(256), IAF_LAYER_FLOATS * sizeof(float), st,
                                    lin, lout, encc, h->d_blob + lp.off, L.RS, L.TE, lp.dilation, tiles_per_row,
-                                   ntiles, (const float*)nullptr, (int64_t)0, HeadF{});
+                                   ntiles, (const float*)nullptr, (int64_t)0, HeadF{}, StartF{});
             float* t = lin; lin = lout; lout = t;
             ++li;
         }
@@ -1258,6 +1326,8 @@ int wn_iaf_set_attrs(wn_handle* h) {
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_head_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_HEAD_FLOATS * sizeof(float)));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_F_FLOATS * sizeof(float)));
+    WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<true, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IAF_LAYER_F_FLOATS * sizeof(float)));
     WN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(iaf_layer_kernel<true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (IAF_LAYER_F_FLOATS + IAF_HEAD_F_FLOATS) * sizeof(float)));
