@@ -42,9 +42,10 @@ def key_of(name):
         return base + targs.replace(' ', '')
     if base in ('deconv_mfma_h_kernel', 'deconv_mfma_hs_kernel'):
         return base + targs.replace(' ', '')
-    if base == 'iaf_layer_kernel':       # fp32 form, template <HOIST, LAST>: hoisted conditioning / the flow head in the epilogue
+    if base == 'iaf_layer_kernel':       # fp32 form, template <HOIST, LAST, START>: hoisted conditioning / the flow head in the epilogue / the start conv in front
         a = [x.strip() for x in targs.strip('<>').split(',')]
-        tag = ','.join(t for t, on in (('hoist', a[0] == 'true'), ('head', len(a) > 1 and a[1] == 'true')) if on)
+        tag = ','.join(t for t, on in (('hoist', a[0] == 'true'), ('head', len(a) > 1 and a[1] == 'true'),
+                                       ('start', len(a) > 2 and a[2] == 'true')) if on)
         return base + ('<' + tag + '>' if tag else '')
     if base == 'gemm_f32_kernel':        # template <NB, DECONV>: the conditioning GEMM / the upsampler's last layer
         a = [x.strip() for x in targs.strip('<>').split(',')]
